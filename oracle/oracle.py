@@ -1,0 +1,137 @@
+"""ctypes binding of oracle/agatha_oracle.c.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product path (agatha_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libagatha_oracle.so")
+_REFLIB = os.path.join(_HERE, "_ref", "libagatha_refshim.so")
+
+
+class Params(C.Structure):
+    """Field order of gasal_subst_scores (reference AGAThA/src/gasal.h:165-173)."""
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open", C.c_int32),
+                ("gap_extend", C.c_int32), ("slice_width", C.c_int32), ("z_threshold", C.c_int32),
+                ("band_width", C.c_int32)]
+
+
+def make_params(m=2, x=4, q=4, r=2, s=3, z=400, w=751):
+    return Params(m, x, q, r, s, z, w)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "agatha_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.agatha_oracle_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_int,
+                                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.agatha_oracle_batch.restype = None
+        _lib.agatha_oracle_pack.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.agatha_nominal_cells.argtypes = [C.c_int, C.c_int, C.c_int]
+        _lib.agatha_nominal_cells.restype = C.c_int64
+    return _lib
+
+
+def make_batch(seqs):
+    """GASAL host-batch wire format (reference host_batch.cpp:79-154): ASCII, each sequence padded
+    with 'N' to a multiple of 8 bytes; returns (bytes array, offsets, lens)."""
+    offs, lens, total = [], [], 0
+    for s in seqs:
+        offs.append(total)
+        lens.append(len(s))
+        total += (len(s) + 7) & ~7
+    buf = np.full(max(total, 8), ord("N"), dtype=np.uint8)
+    for s, o in zip(seqs, offs):
+        if len(s):
+            buf[o:o + len(s)] = np.frombuffer(s if isinstance(s, bytes) else s.encode(), dtype=np.uint8)
+    return buf[:total] if total else buf[:0], np.asarray(offs, np.uint32), np.asarray(lens, np.uint32)
+
+
+MODEL_SLICES, MODEL_STEPS, MODEL_EXACTBAND = 0, 1, 2
+
+
+def align_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, wide=False, model=MODEL_SLICES, threads=1):
+    n = len(qlen)
+    qbuf = np.ascontiguousarray(qbuf, np.uint8)
+    tbuf = np.ascontiguousarray(tbuf, np.uint8)
+    arrs = [np.ascontiguousarray(a, np.uint32) for a in (qoff, toff, qlen, tlen)]
+    out = np.zeros((3, n), np.int32)
+    lib().agatha_oracle_batch(qbuf.ctypes.data, tbuf.ctypes.data, *[a.ctypes.data for a in arrs], n,
+                              C.byref(params), int(wide), int(model), int(threads),
+                              out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data)
+    return out[0], out[1], out[2]
+
+
+def align_pairs(queries, targets, params, **kw):
+    qb, qo, ql = make_batch(queries)
+    tb, to, tl = make_batch(targets)
+    return align_batch(qb, tb, qo, to, ql, tl, params, **kw)
+
+
+def pack(unpacked):
+    unpacked = np.ascontiguousarray(unpacked, np.uint8)
+    assert unpacked.size % 8 == 0
+    out = np.zeros(unpacked.size // 8, np.uint32)
+    lib().agatha_oracle_pack(unpacked.ctypes.data, unpacked.size, out.ctypes.data)
+    return out
+
+
+def nominal_cells(Q, R, w):
+    return int(lib().agatha_nominal_cells(int(Q), int(R), int(w)))
+
+
+def nominal_cells_np(qlen, tlen, w):
+    """Vectorised nominal in-band cell count: sum_i (min(R-1,i+w)-max(0,i-w)+1)."""
+    tot = 0
+    for Q, R in zip(np.asarray(qlen, np.int64), np.asarray(tlen, np.int64)):
+        i = np.arange(Q, dtype=np.int64)
+        hi = np.minimum(R - 1, i + w)
+        lo = np.maximum(0, i - w)
+        tot += int(np.clip(hi - lo + 1, 0, None).sum())
+    return tot
+
+
+# ---- the reference kernel itself under the CPU warp emulator (only where oracle/_ref was built) ----
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(_REFLIB)
+
+
+def ref_align_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, blocks=0, threads_per_block=256):
+    """Run the unmodified reference agatha_kernel on CPU (oracle/ref_shim).  Only available in the
+    build container after `make -C oracle ref`."""
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(_REFLIB)
+        _ref.refshim_align.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_int,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        _ref.refshim_align.restype = C.c_int
+    n = len(qlen)
+    qbuf = np.ascontiguousarray(qbuf, np.uint8)
+    tbuf = np.ascontiguousarray(tbuf, np.uint8)
+    arrs = [np.ascontiguousarray(a, np.uint32) for a in (qoff, toff, qlen, tlen)]
+    out = np.zeros((3, n), np.int32)
+    rc = _ref.refshim_align(qbuf.ctypes.data, tbuf.ctypes.data, *[a.ctypes.data for a in arrs], n,
+                            C.byref(params), int(blocks), int(threads_per_block),
+                            out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data)
+    if rc != 0:
+        raise RuntimeError("reference shim reported deadlock/error rc=%d" % rc)
+    return out[0], out[1], out[2]
