@@ -1,0 +1,77 @@
+"""CPU-only: the oracle against the reference's known answers, and its two schedules against each other."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O, synth
+from helpers import load_kats, load_ref_vectors, oracle_batch
+
+
+@pytest.mark.parametrize("model", [O.MODEL_SLICES, O.MODEL_STEPS])
+@pytest.mark.parametrize("wide", [False, True])
+def test_appendix_e_kats(model, wide):
+    doc = load_kats()
+    for c in doc["cases"]:
+        s, q, t = O.align_pairs([c["query"]], [c["target"]], O.make_params(**c["params"]), wide=wide, model=model)
+        assert [int(s[0]), int(q[0]), int(t[0])] == c["expect"], (c["id"], c["params"], c["note"])
+
+
+def test_int16_saturation_kat():
+    sat = load_kats()["saturation"]
+    rng = np.random.default_rng(sat["seed"])
+    seq = "".join(rng.choice(list("ACGT"), sat["length"]))
+    for model in (O.MODEL_SLICES, O.MODEL_STEPS):
+        s, q, t = O.align_pairs([seq], [seq], O.make_params(), wide=False, model=model)
+        assert [int(s[0]), int(q[0]), int(t[0])] == sat["expect_faithful"]
+        s, q, t = O.align_pairs([seq], [seq], O.make_params(), wide=True, model=model)
+        assert [int(s[0]), int(q[0]), int(t[0])] == sat["expect_wide"]
+
+
+@pytest.mark.parametrize("g", load_ref_vectors(), ids=lambda g: g["name"])
+def test_reference_vectors(g):
+    """Outputs of the reference kernel (run under oracle/ref_shim when the fixture was generated)."""
+    for wide, model in ((False, O.MODEL_SLICES), (True, O.MODEL_STEPS)):
+        if model == O.MODEL_STEPS and g["qlen"].max() > 12000:
+            pass
+        s, q, t = oracle_batch(g, wide=wide, model=model, threads=4)
+        exp = g["expect"]
+        assert (s == exp[0]).all() and (q == exp[1]).all() and (t == exp[2]).all()
+
+
+def test_slices_equals_steps_random():
+    rng = np.random.default_rng(11)
+    for _ in range(60):
+        w = int(rng.choice([0, 1, 3, 5, 8, 9, 16, 17, 33, 64, 100, 751]))
+        P = O.make_params(m=2, x=4, q=4, r=int(rng.choice([1, 2])), s=int(rng.choice([1, 2, 3, 5, 7])),
+                          z=int(rng.choice([-1, 0, 20, 100, 400])), w=w)
+        e = float(rng.uniform(0, 0.15))
+        qs, ts = synth.make_pairs(int(rng.integers(1 << 30)), 16, lambda r: int(np.exp(r.uniform(0, np.log(1200)))),
+                                  e, e, e, n_rate=0.01)
+        if rng.random() < 0.4:
+            ts = [t[: max(1, len(t) // 3)] for t in ts]
+        for wide in (False, True):
+            a = O.align_pairs(qs, ts, P, wide=wide, model=O.MODEL_SLICES)
+            b = O.align_pairs(qs, ts, P, wide=wide, model=O.MODEL_STEPS)
+            assert all((x == y).all() for x, y in zip(a, b))
+
+
+def test_exact_band_model_agrees_at_wide_bands():
+    """At the BASELINE bands the textbook |i-j|<=w model agrees with the block-granular reference semantics."""
+    qs, ts = synth.make_pairs(5, 24, lambda r: int(r.integers(500, 3000)), 0.03, 0.03, 0.04)
+    for w in (101, 751):
+        P = O.make_params(w=w)
+        a = O.align_pairs(qs, ts, P, wide=True, model=O.MODEL_SLICES)
+        b = O.align_pairs(qs, ts, P, model=O.MODEL_EXACTBAND)
+        assert all((x == y).all() for x, y in zip(a, b))
+
+
+def test_pack_layout():
+    buf, off, ln = O.make_batch([b"ACGTNACG", b"TT"])
+    p = O.pack(buf)
+    # first base in bits 31-28; A=1 C=3 G=7 T=4 N=14 (reference pack_rc_seqs.h:21-33)
+    assert p[0] == 0x1374E137 and p[1] == 0x44EEEEEE
+
+
+def test_nominal_cells_formula():
+    L, w = 10000, 751
+    assert O.nominal_cells(L, L, w) == L * (2 * w + 1) - w * (w + 1) == 14465248
+    assert O.nominal_cells_np([L], [L], w) == 14465248
