@@ -1,0 +1,478 @@
+// align_kernel.hip -- banded affine-gap extension DP with z-drop for MI355X (gfx950, wave64).
+//
+// Replaces the reference's agatha_kernel (AGAThA/src/kernels/agatha_kernel.h:49-431) and its
+// length sort (agatha_sort :434-458 + the host std::sort in gasal_align.cu:14-18).  Results are
+// bit-identical to the reference wherever the reference is defined (lengths < 32768, |H| < 32768);
+// outside that domain the arithmetic simply stays int32 ("wide" semantics).
+//
+// Design (not a translation of the CUDA kernel):
+//   * one sequence pair per G-lane sub-wavefront (G = 16/32/64), 64/G pairs per wave, no LDS state,
+//     no global scratch (the reference keeps 3 strips of L entries per subwarp in global memory).
+//   * the DP advances one BLOCK-anti-diagonal ("step") at a time; column block r is owned for its
+//     whole life by slot r % S of lane (r / S) % G, so the column state (H, F of 8 columns) never
+//     leaves VGPRs.  The row state (H, E of 8 rows) of block (q, r) is the input of block (q, r+1)
+//     one step later: next slot of the same lane, or lane+1 through one cross-lane rotate.
+//   * the per-anti-diagonal maximum (value + largest column) is a packed key (H << K) + column
+//     relative to a moving base, accumulated in 15 registers per lane and reduced over the group
+//     once per step; z-drop is tested eagerly every step, which is equivalent to the reference's
+//     per-slice test (oracle/agatha_oracle.c: agatha_model_steps == agatha_model_slices).
+//   * pairs are pulled longest-first from an atomic queue by whichever group is free
+//     (the reference's uneven bucketing + subwarp rejoining solve the same imbalance differently).
+//
+// The lane-for-lane CPU emulation of exactly this schedule is oracle/agatha_lanes_model.c.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+
+#include "kernels.h"
+
+namespace agatha {
+
+#define NEG_INF2 (-16384)   // SHRT_MIN/2: the reference's -infinity (gasal_kernels.h:39)
+#define N_VALUE 14u         // 'N' & 0xF (AGAThA/Makefile:4)
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
+
+// value of lane `src` (absolute lane id) -- ds_bpermute_b32, no LDS storage involved
+__device__ __forceinline__ int lane_read(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+
+// max over the G lanes of a group, result in every lane
+template <int G>
+__device__ __forceinline__ int group_max(int v, int lane)
+{
+    // rotations inside a 16-lane DPP row: row_ror:1,2,4,8
+    v = imax(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));
+    v = imax(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));
+    v = imax(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));
+    v = imax(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
+    if (G >= 32) v = imax(v, lane_read(v, lane ^ 16));
+    if (G >= 64) v = imax(v, lane_read(v, lane ^ 32));
+    return v;
+}
+
+template <int GS> struct KeyBits {          // smallest K with 2^K >= 8 * (GS + 2)
+    static constexpr int value = (8 * (GS + 2) <= 128) ? 7 : (8 * (GS + 2) <= 256) ? 8 : (8 * (GS + 2) <= 512) ? 9
+                               : (8 * (GS + 2) <= 1024) ? 10 : (8 * (GS + 2) <= 2048) ? 11 : (8 * (GS + 2) <= 4096) ? 12 : 13;
+};
+
+// initial column state of column block r: H(-1, c), F(0, c)  (agatha_kernel.h:133-148, 207-215)
+__device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge, int (&h)[8], int (&f)[8], int& corner)
+{
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const int c = 8 * r + m;
+        const int k = -(gapoe + ge * c);
+        const bool in = (c < R) && (c <= w);
+        h[m] = in ? k : NEG_INF2;
+        f[m] = in ? k - gapoe : NEG_INF2;
+    }
+    const int kc = -(gapoe + ge * (8 * r - 1));
+    corner = (r == 0) ? 0 : ((8 * r - 1) <= w ? kc : NEG_INF2);
+}
+
+// One 8x8 block (q, r): the reference's CORE_COMPUTE / CORE_COMPUTE_BOUNDARY sweep
+// (agatha_kernel.h:20-46, 230-269) on register state.
+//   h, f    column state H(row above, c), F(next row, c) of the 8 columns       (in/out)
+//   corner  H(row above, column left of the block)                             (in/out)
+//   rh      H(row, column left of the block) for the 8 rows                    (in)
+//   e       E(row, first column) in, E(row, column right of the block) out     (in/out)
+//   oh      H(row, last column) out
+// MASKED: per-cell band test of boundary blocks and the row limit of the last row block, as EXEC masks
+//         built once per block (km: one lane mask per cell diagonal jl-il, rm: one per row).
+// HAS_N : either word holds an N (score -1, gasal_kernels.h:48-50); otherwise the N test is dropped.
+template <bool MASKED, bool HAS_N, int K>
+__device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, const int (&rh)[8], int (&e)[8],
+                                         int (&oh)[8], int (&A)[15], uint32_t qword, uint32_t rword,
+                                         int va, int vnb, int gapoe, int ge, int crel0, int nrows, int tu, int tl)
+{
+    uint32_t rb[8];
+    int cj[8];
+#pragma unroll
+    for (int jl = 0; jl < 8; jl++) { rb[jl] = (rword >> (28 - 4 * jl)) & 15u; cj[jl] = crel0 + jl; }
+    unsigned long long km[15], rm[8];
+    if (MASKED) {
+#pragma unroll
+        for (int kk = 0; kk < 15; kk++) km[kk] = __builtin_amdgcn_ballot_w64((kk - 7) <= tu && (7 - kk) <= tl);
+#pragma unroll
+        for (int il = 0; il < 8; il++) rm[il] = __builtin_amdgcn_ballot_w64(il < nrows);
+    }
+#pragma unroll
+    for (int il = 0; il < 8; il++) {
+        if (!MASKED || __builtin_amdgcn_inverse_ballot_w64(rm[il])) {
+            const uint32_t qb = (qword >> (28 - 4 * il)) & 15u;
+            int t[8];
+#pragma unroll
+            for (int jl = 0; jl < 8; jl++) {
+                int sc = (qb == rb[jl]) ? va : vnb;
+                if (HAS_N) sc = (qb == N_VALUE || rb[jl] == N_VALUE) ? -1 : sc;
+                const int d = (jl == 0) ? ((il == 0) ? corner : rh[il - 1]) : h[jl - 1];
+                t[jl] = sc + d;
+            }
+            // every diagonal term is taken from the PREVIOUS row's H: pin them before H is overwritten
+#pragma unroll
+            for (int jl = 0; jl < 8; jl++) asm volatile("" : "+v"(t[jl]));
+            int ev = e[il];
+#pragma unroll
+            for (int jl = 0; jl < 8; jl++) {
+                if (!MASKED || __builtin_amdgcn_inverse_ballot_w64(km[jl - il + 7])) {
+                    const int hn = imax3(t[jl], f[jl], ev);
+                    const int tg = t[jl] - gapoe;
+                    f[jl] = imax(tg, f[jl] - ge);
+                    ev = imax(tg, ev - ge);
+                    h[jl] = hn;
+                    A[il + jl] = imax(A[il + jl], (int)(((uint32_t)hn << K) + (uint32_t)cj[jl]));
+                }
+            }
+            oh[il] = h[7]; e[il] = ev;
+            corner = rh[il];                       // p[1] = h[0] of the last processed row (agatha_kernel.h:28)
+        }
+    }
+}
+
+__device__ __forceinline__ bool word_has_n(uint32_t v)
+{
+    const uint32_t x = v ^ 0xEEEEEEEEu;            // a zero nibble <=> an N
+    return ((x - 0x11111111u) & ~x & 0x88888888u) != 0u;
+}
+
+template <int G, int S>
+__global__ void __launch_bounds__(256, (S <= 3 ? 2 : 1))
+align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__ packed_t,
+             const uint32_t* __restrict__ qlens, const uint32_t* __restrict__ tlens,
+             const uint32_t* __restrict__ qoffs, const uint32_t* __restrict__ toffs,
+             const uint32_t* __restrict__ order, int n, unsigned int* __restrict__ queue,
+             int32_t* __restrict__ out_score, int32_t* __restrict__ out_qend, int32_t* __restrict__ out_tend,
+             AlignParams P)
+{
+    constexpr int GS = G * S;
+    constexpr int K = KeyBits<GS>::value;
+    constexpr int KMASK = (1 << K) - 1;
+
+    const int lane = threadIdx.x & 63;
+    const int k = lane & (G - 1);                 // lane inside the group
+    const int gbase = lane & ~(G - 1);            // first lane of the group
+    const int left_lane = gbase | ((k + G - 1) & (G - 1));
+
+    const int gapoe = P.gap_open + P.gap_extend, ge = P.gap_extend;
+    const int sw = P.slice_width, z = P.z_threshold, w = P.band_width;
+    const int W = (w + 7) >> 3;
+    int va = P.match, vnb = -P.mismatch;          // kept in VGPRs: both arms of the score select
+    asm volatile("" : "+v"(va), "+v"(vnb));
+
+    // ---- per-pair state (uniform inside a group) ----
+    int Q = 0, R = 0, pql = 0, prl = 0, total = 0, lim = 0, pair = 0;
+    const uint32_t* pq = packed_q;
+    const uint32_t* pt = packed_t;
+    int i = 0, y = 0, ss = 0, se = 0, cb_prev = 0;
+    bool alive = false, exhausted = false, final_step = false;
+    int best = 0, best_t = 0, best_q = 0;
+
+    // ---- per-lane state ----
+    int rcur[S], corner[S];
+    int h[S][8], f[S][8];
+    uint32_t rword[S];
+    int xh[S + 1][8], xe[S + 1][8], xr[S + 1];   // hand-off: X[s] feeds slot s, X[S] leaves slot S-1
+    int A[15];
+
+#pragma unroll
+    for (int s = 0; s < S; s++) { rcur[s] = 0; corner[s] = 0; rword[s] = 0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) { h[s][m] = 0; f[s][m] = 0; } }
+#pragma unroll
+    for (int s = 0; s <= S; s++) { xr[s] = -2;
+#pragma unroll
+        for (int m = 0; m < 8; m++) { xh[s][m] = 0; xe[s][m] = 0; } }
+#pragma unroll
+    for (int x = 0; x < 15; x++) A[x] = INT_MIN;
+
+    for (;;) {
+        // ------------------------------------------------------------------ work queue
+        const bool need = !alive && !exhausted;
+        if (__any(need)) {
+            int idx = 0;
+            if (need && k == 0) idx = (int)atomicAdd(queue, 1u);
+            idx = lane_read(idx, gbase);
+            if (need) {
+                if (idx >= n) exhausted = true;
+                else {
+                    pair = (int)order[idx];
+                    Q = (int)qlens[pair]; R = (int)tlens[pair];
+                    pq = packed_q + (qoffs[pair] >> 3);
+                    pt = packed_t + (toffs[pair] >> 3);
+                    pql = (Q + 7) >> 3; prl = (R + 7) >> 3;
+                    total = prl + pql - 1; lim = Q + R - 1;
+                    best = 0; best_t = 0; best_q = 0;
+                    i = 0; y = 0; cb_prev = 0; final_step = false;
+                    ss = 0;
+                    se = imin(imin(prl - 1, sw - 1), (((sw - 1) * 8 + 7 + w) / 2) / 8);
+#pragma unroll
+                    for (int s = 0; s < S; s++) {
+                        rcur[s] = k * S + s;
+                        init_col(rcur[s], R, w, gapoe, ge, h[s], f[s], corner[s]);
+                        rword[s] = (rcur[s] < prl) ? pt[rcur[s]] : 0xEEEEEEEEu;
+                    }
+#pragma unroll
+                    for (int s = 0; s <= S; s++) xr[s] = -2;
+#pragma unroll
+                    for (int x = 0; x < 15; x++) A[x] = INT_MIN;
+                    alive = true;
+                    if (Q <= 0 || R <= 0) {           // nothing to align
+                        if (k == 0) { out_score[pair] = 0; out_qend[pair] = 0; out_tend[pair] = 0; }
+                        alive = false;
+                    }
+                }
+            }
+        }
+        if (!__any(alive)) break;
+
+        // ------------------------------------------------------------------ one step
+        // column base of the packed maxima: one block left of the lowest active column block
+        const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
+        {
+            const int delta = cb - cb_prev;       // 0 or 8; saturating so that the empty marker INT_MIN survives
+#pragma unroll
+            for (int x = 0; x < 7; x++) A[x] = __builtin_elementwise_sub_sat(A[x], delta);
+        }
+
+#pragma unroll
+        for (int s = S - 1; s >= 0; s--) {
+            const int r = rcur[s], q = i - r;
+            const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
+            const bool active = alive && !final_step && r < prl && q >= cs && q <= ce && r >= ss && r <= se;
+            xr[s + 1] = active ? r : -2;
+            uint32_t qword = 0;
+            if (active) qword = pq[q];
+            const uint32_t rw = rword[s];
+            const int nrows = imin(8, Q - 8 * q);
+            const bool boundary = (q == cs) || (q == ce);               // agatha_kernel.h:243
+            if (active) {
+                if (y == 0 && r == prl - 1) {   // pass start: padded ref columns fall back to -inf (agatha_kernel.h:207-215)
+#pragma unroll
+                    for (int m = 0; m < 8; m++) if (8 * r + m >= R) { h[s][m] = NEG_INF2; f[s][m] = NEG_INF2; }
+                }
+                const bool left_ok = (xr[s] == r - 1);
+                int rh[8];
+#pragma unroll
+                for (int il = 0; il < 8; il++) {
+                    const int row = 8 * q + il;
+                    const int kk = -(gapoe + ge * row);
+                    const int ih = (row <= w) ? kk : NEG_INF2;            // H(row, -1)   (agatha_kernel.h:126-131)
+                    const int ie = (row <= w) ? kk - gapoe : NEG_INF2;    // E(row, 0)
+                    rh[il] = left_ok ? xh[s][il] : ih;
+                    xe[s + 1][il] = left_ok ? xe[s][il] : ie;             // E travels in place through the block
+                }
+                const int tu = boundary ? w + 8 * q - 8 * r : 1000;     // cell skipped when jl - il > tu (:33)
+                const int tl = boundary ? w - 8 * q + 8 * r : 1000;     //                or il - jl > tl
+                const int crel0 = 8 * r - cb;
+                // one generic variant: edge blocks (band test) exist on every anti-diagonal, so a mask-free
+                // variant would rarely run for a whole wave and only costs instruction-cache space
+                block8x8<true, true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, va, vnb, gapoe, ge, crel0, nrows, tu, tl);
+            }
+        }
+        // X[S] of the left neighbour lane becomes X[0]
+#pragma unroll
+        for (int il = 0; il < 8; il++) { xh[0][il] = lane_read(xh[S][il], left_lane); xe[0][il] = lane_read(xe[S][il], left_lane); }
+        xr[0] = lane_read(xr[S], left_lane);
+
+        // ------------------------------------------------------------------ anti-diagonals 8i..8i+7 are complete
+        bool stopped = false;
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            const int v = group_max<G>(A[x], lane);
+            const int d = 8 * i + x;
+            const bool chk = alive && !stopped && (final_step || d < lim);           // agatha_kernel.h:293-294 / 337
+            int H = v >> K, c = (v & KMASK) + cb;
+            if (v == INT_MIN) { H = -32768; c = 0; }                                  // empty anti-diagonal
+            if (chk) {                                                               // agatha_kernel.h:297-309
+                if (H > best) { best = H; best_t = c; best_q = d - c; }
+                else if (c >= best_t && (d - c) >= best_q) {
+                    const int tlen = c - best_t, qlen = (d - c) - best_q;
+                    const int l = tlen > qlen ? tlen - qlen : qlen - tlen;
+                    if (z >= 0 && best - H > z + l * ge) stopped = true;
+                }
+            }
+        }
+        bool finished = alive && (stopped || final_step);
+
+        // carry dl 8..14 into the next step
+#pragma unroll
+        for (int x = 0; x < 7; x++) A[x] = A[8 + x];
+#pragma unroll
+        for (int x = 7; x < 15; x++) A[x] = INT_MIN;
+        cb_prev = cb;
+
+        // slots whose column block has left the band move on to column r + G*S
+        bool adv[S];
+        bool any_adv = false;
+#pragma unroll
+        for (int s = 0; s < S; s++) { adv[s] = alive && (i + 1 - rcur[s] > imin(pql - 1, rcur[s] + W)); any_adv |= adv[s]; }
+        if (__any(any_adv)) {
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                if (adv[s]) {
+                    const int rn = rcur[s] + GS;
+                    rcur[s] = rn;
+                    init_col(rn, R, w, gapoe, ge, h[s], f[s], corner[s]);
+                    rword[s] = (rn < prl) ? pt[rn] : 0xEEEEEEEEu;
+                }
+            }
+        }
+
+        // next step / next slice (agatha_kernel.h:183-191, 330-334)
+        i++; y++;
+        if (y == sw) {
+            y = 0;
+            if (i >= total) final_step = true;
+            else {
+                ss = imax(imax(0, i - pql + 1), ((i * 8 + 8 - w) / 2) / 8);
+                se = imin(imin(prl - 1, i + sw - 1), (((i + sw - 1) * 8 + 7 + w) / 2) / 8);
+                if (ss > se) finished = alive;       // empty slice: stop without checking it (:189-191)
+            }
+        }
+        if (finished) {
+            if (k == 0) { out_score[pair] = best; out_qend[pair] = best_q; out_tend[pair] = best_t; }   // :359-363
+            alive = false;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Length sort on the device (the reference does it on the host inside the timed region,
+// gasal_align.cu:14-18): counting sort of pair ids by step count, longest first.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sort_key(uint32_t ql, uint32_t tl, uint32_t nbuckets)
+{
+    const uint32_t steps = ((ql + 7) >> 3) + ((tl + 7) >> 3);       // total block anti-diagonals + 1
+    const uint32_t b = steps >> 2;                                   // 32-base granularity is plenty
+    return b < nbuckets ? b : nbuckets - 1;
+}
+
+__global__ void sort_hist_kernel(const uint32_t* __restrict__ qlens, const uint32_t* __restrict__ tlens, int n,
+                                 uint32_t* __restrict__ hist, uint32_t nbuckets)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) atomicAdd(&hist[sort_key(qlens[t], tlens[t], nbuckets)], 1u);
+}
+
+// one workgroup: exclusive scan of the histogram from the LONGEST bucket down
+__global__ void sort_scan_kernel(uint32_t* __restrict__ hist, uint32_t nbuckets)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t per = (nbuckets + 255) / 256;
+    const uint32_t t = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t b = t * per + j;
+        if (b < nbuckets) sum += hist[nbuckets - 1 - b];
+    }
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) { uint32_t acc = 0; for (int j = 0; j < 256; j++) { const uint32_t v = part[j]; part[j] = acc; acc += v; } }
+    __syncthreads();
+    uint32_t acc = part[t];
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t b = t * per + j;
+        if (b < nbuckets) { const uint32_t v = hist[nbuckets - 1 - b]; hist[nbuckets - 1 - b] = acc; acc += v; }
+    }
+}
+
+__global__ void sort_scatter_kernel(const uint32_t* __restrict__ qlens, const uint32_t* __restrict__ tlens, int n,
+                                    uint32_t* __restrict__ cursor, uint32_t nbuckets, uint32_t* __restrict__ order)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) order[atomicAdd(&cursor[sort_key(qlens[t], tlens[t], nbuckets)], 1u)] = (uint32_t)t;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ASCII -> 4-bit packing, 8 bases per uint32, first base in bits 31-28 (replaces gasal_pack_kernel,
+// pack_rc_seqs.h:13-53).  16 input bytes -> 8 output bytes per lane per iteration, fully coalesced.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack8(uint32_t lo, uint32_t hi)
+{
+    // byte k of (lo, hi) -> nibble 7-k
+    uint32_t v = 0;
+    v |= (lo & 15u) << 28; v |= ((lo >> 8) & 15u) << 24; v |= ((lo >> 16) & 15u) << 20; v |= ((lo >> 24) & 15u) << 16;
+    v |= (hi & 15u) << 12; v |= ((hi >> 8) & 15u) << 8; v |= ((hi >> 16) & 15u) << 4; v |= ((hi >> 24) & 15u);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+pack_kernel(const uint4* __restrict__ in16, uint2* __restrict__ out8, uint32_t n16,
+            const uint2* __restrict__ in8_tail, uint32_t* __restrict__ out4_tail, uint32_t has_tail)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n16; t += stride) {
+        const uint4 v = in16[t];
+        uint2 o; o.x = pack8(v.x, v.y); o.y = pack8(v.z, v.w);
+        out8[t] = o;
+    }
+    if (has_tail && blockIdx.x == 0 && threadIdx.x == 0) { const uint2 v = *in8_tail; *out4_tail = pack8(v.x, v.y); }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side launchers (called from capi.cpp through kernels.h)
+// ---------------------------------------------------------------------------------------------------
+template <int G, int S>
+static hipError_t launch_align_t(const AlignLaunch& L, hipStream_t st)
+{
+    // enough groups for every pair, capped by what the chip can keep resident (2 waves/SIMD = 8 waves/CU)
+    const int groups_per_block = (256 / 64) * (64 / G);
+    int blocks = (L.n + groups_per_block - 1) / groups_per_block;
+    const int max_blocks = L.num_cus * 2;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((align_kernel<G, S>), dim3(blocks), dim3(256), 0, st,
+                       L.packed_q, L.packed_t, L.qlens, L.tlens, L.qoffs, L.toffs, L.order, L.n, L.queue,
+                       L.score, L.qend, L.tend, L.p);
+    return hipGetLastError();
+}
+
+struct Cfg { int G, S; hipError_t (*fn)(const AlignLaunch&, hipStream_t); };
+static const Cfg kCfgs[] = {
+    {16, 1, launch_align_t<16, 1>}, {16, 2, launch_align_t<16, 2>}, {16, 3, launch_align_t<16, 3>},
+    {32, 2, launch_align_t<32, 2>}, {32, 3, launch_align_t<32, 3>},
+    {64, 2, launch_align_t<64, 2>}, {64, 3, launch_align_t<64, 3>}, {64, 4, launch_align_t<64, 4>},
+    {64, 6, launch_align_t<64, 6>},
+};
+
+int max_window_blocks() { return 64 * 6; }
+
+hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint32_t* hist, uint32_t nbuckets,
+                       uint32_t* order, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(hist, 0, sizeof(uint32_t) * nbuckets, st);
+    if (e != hipSuccess) return e;
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(blocks), dim3(256), 0, st, qlens, tlens, n, hist, nbuckets);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(256), 0, st, hist, nbuckets);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks), dim3(256), 0, st, qlens, tlens, n, hist, nbuckets, order);
+    return hipGetLastError();
+}
+
+hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st)
+{
+    for (const Cfg& c : kCfgs) {
+        if (c.G * c.S >= window_blocks) {
+            if (G_out) *G_out = c.G;
+            if (S_out) *S_out = c.S;
+            return c.fn(L, st);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_pack(const uint8_t* unpacked, uint32_t nbytes, uint32_t* packed, hipStream_t st)
+{
+    const uint32_t n16 = nbytes / 16, tail = (nbytes % 16) ? 1u : 0u;    // nbytes is a multiple of 8
+    uint32_t blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st,
+                       reinterpret_cast<const uint4*>(unpacked), reinterpret_cast<uint2*>(packed), n16,
+                       reinterpret_cast<const uint2*>(unpacked + (size_t)n16 * 16), packed + (size_t)n16 * 2, tail);
+    return hipGetLastError();
+}
+
+}  // namespace agatha

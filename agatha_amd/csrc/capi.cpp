@@ -1,0 +1,151 @@
+// capi.cpp -- the C-ABI of include/agatha_amd.h on top of the HIP kernels.
+#include "../../include/agatha_amd.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_err[256] = "";
+thread_local int g_lastG = 0, g_lastS = 0;
+
+int hip_fail(hipError_t e, const char* what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s (HIP error %d)", what, hipGetErrorString(e), (int)e);
+    return AGATHA_AMD_EHIP;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+constexpr uint32_t kBuckets = 16384;     // sort buckets of 32 bases of (query + target) length
+constexpr size_t kAlign = 256;
+size_t round_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+int num_cus()
+{
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        hipDeviceProp_t prop;
+        cached = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* agatha_amd_strerror(int code)
+{
+    switch (code) {
+        case AGATHA_AMD_OK: return "ok";
+        case AGATHA_AMD_EINVAL: return "invalid argument";
+        case AGATHA_AMD_EBAND: return "band wider than the largest compiled window";
+        case AGATHA_AMD_EWORKSPACE: return "workspace too small";
+        case AGATHA_AMD_EHIP: return "HIP runtime error";
+        default: return "unknown error";
+    }
+}
+const char* agatha_amd_last_error(void) { return g_err; }
+const char* agatha_amd_version(void) { return "agatha_amd 0.1 (gfx950)"; }
+
+int agatha_amd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int agatha_amd_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
+
+int agatha_amd_max_band(void) { return (agatha::max_window_blocks() - 1) * 8; }
+
+size_t agatha_amd_workspace_bytes(uint32_t max_n_alns)
+{
+    return round_up(sizeof(uint32_t) * (size_t)max_n_alns) + round_up(sizeof(uint32_t) * kBuckets) + kAlign;
+}
+
+int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, uint32_t* d_packed)
+{
+    if (!d_unpacked || !d_packed || nbytes == 0 || (nbytes % 8) != 0) return AGATHA_AMD_EINVAL;
+    HIPCHK(agatha::launch_pack(d_unpacked, nbytes, d_packed, (hipStream_t)stream));
+    return 0;
+}
+
+int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
+                     const uint32_t* d_query_lens, const uint32_t* d_target_lens,
+                     const uint32_t* d_query_offsets, const uint32_t* d_target_offsets,
+                     uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
+                     const agatha_amd_scores* sc, int32_t* d_aln_score, int32_t* d_query_batch_end,
+                     int32_t* d_target_batch_end, void* d_workspace, size_t workspace_bytes)
+{
+    if (!d_packed_query || !d_packed_target || !d_query_lens || !d_target_lens || !d_query_offsets ||
+        !d_target_offsets || !sc || !d_aln_score || !d_query_batch_end || !d_target_batch_end || !d_workspace)
+        return AGATHA_AMD_EINVAL;
+    if (n_alns == 0 || n_alns > 0x7fffffffu) return AGATHA_AMD_EINVAL;
+    if (sc->slice_width < 1 || sc->band_width < 0 || sc->gap_extend < 0) return AGATHA_AMD_EINVAL;
+    if (workspace_bytes < agatha_amd_workspace_bytes(n_alns)) return AGATHA_AMD_EWORKSPACE;
+
+    // blocks that can be live on one block-anti-diagonal: min(W + 1, ceil(Q/8), ceil(R/8))
+    const long W = ((long)sc->band_width + 7) / 8;
+    long window = W + 1;
+    if (max_query_len) window = std::min(window, ((long)max_query_len + 7) / 8);
+    if (max_target_len) window = std::min(window, ((long)max_target_len + 7) / 8);
+    window = std::max(window, 1L);
+    if (window > agatha::max_window_blocks()) return AGATHA_AMD_EBAND;
+
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)d_workspace;
+    uint32_t* order = (uint32_t*)ws;             ws += round_up(sizeof(uint32_t) * (size_t)n_alns);
+    uint32_t* hist = (uint32_t*)ws;              ws += round_up(sizeof(uint32_t) * kBuckets);
+    unsigned int* queue = (unsigned int*)ws;
+
+    HIPCHK(agatha::launch_sort(d_query_lens, d_target_lens, (int)n_alns, hist, kBuckets, order, st));
+    HIPCHK(hipMemsetAsync(queue, 0, sizeof(unsigned int), st));
+
+    agatha::AlignLaunch L;
+    L.packed_q = d_packed_query; L.packed_t = d_packed_target;
+    L.qlens = d_query_lens; L.tlens = d_target_lens; L.qoffs = d_query_offsets; L.toffs = d_target_offsets;
+    L.order = order; L.n = (int)n_alns; L.queue = queue;
+    L.score = d_aln_score; L.qend = d_query_batch_end; L.tend = d_target_batch_end;
+    L.p = {sc->match, sc->mismatch, sc->gap_open, sc->gap_extend, sc->slice_width, sc->z_threshold, sc->band_width};
+    L.num_cus = num_cus();
+    HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st));
+    return 0;
+}
+
+void agatha_amd_last_config(int* G, int* S) { if (G) *G = g_lastG; if (S) *S = g_lastS; }
+
+int agatha_amd_malloc(void** d_ptr, size_t bytes) { if (!d_ptr) return AGATHA_AMD_EINVAL; HIPCHK(hipMalloc(d_ptr, bytes ? bytes : 1)); return 0; }
+int agatha_amd_free(void* d_ptr) { if (d_ptr) HIPCHK(hipFree(d_ptr)); return 0; }
+int agatha_amd_host_alloc(void** h_ptr, size_t bytes) { if (!h_ptr) return AGATHA_AMD_EINVAL; HIPCHK(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault)); return 0; }
+int agatha_amd_host_free(void* h_ptr) { if (h_ptr) HIPCHK(hipHostFree(h_ptr)); return 0; }
+int agatha_amd_memcpy_h2d_async(void* stream, void* d_dst, const void* h_src, size_t bytes)
+{ if (bytes) HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); return 0; }
+int agatha_amd_memcpy_d2h_async(void* stream, void* h_dst, const void* d_src, size_t bytes)
+{ if (bytes) HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); return 0; }
+int agatha_amd_stream_create(void** stream) { if (!stream) return AGATHA_AMD_EINVAL; hipStream_t s; HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = (void*)s; return 0; }
+int agatha_amd_stream_destroy(void* stream) { if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream)); return 0; }
+int agatha_amd_stream_synchronize(void* stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int agatha_amd_stream_query(void* stream)
+{
+    hipError_t e = hipStreamQuery((hipStream_t)stream);
+    if (e == hipSuccess) return 0;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
+    return hip_fail(e, "hipStreamQuery");
+}
+int agatha_amd_event_create(void** event) { if (!event) return AGATHA_AMD_EINVAL; hipEvent_t e; HIPCHK(hipEventCreate(&e)); *event = (void*)e; return 0; }
+int agatha_amd_event_destroy(void* event) { if (event) HIPCHK(hipEventDestroy((hipEvent_t)event)); return 0; }
+int agatha_amd_event_record(void* event, void* stream) { HIPCHK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); return 0; }
+int agatha_amd_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+    if (!ms) return AGATHA_AMD_EINVAL;
+    HIPCHK(hipEventSynchronize((hipEvent_t)stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// kernels.h -- private interface between the C-ABI (capi.cpp) and the HIP kernels (align_kernel.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace agatha {
+
+// field order of the reference's gasal_subst_scores (AGAThA/src/gasal.h:165-173)
+struct AlignParams { int32_t match, mismatch, gap_open, gap_extend, slice_width, z_threshold, band_width; };
+
+struct AlignLaunch {
+    const uint32_t *packed_q, *packed_t, *qlens, *tlens, *qoffs, *toffs, *order;
+    int n;
+    unsigned int* queue;
+    int32_t *score, *qend, *tend;
+    AlignParams p;
+    int num_cus;
+};
+
+// window_blocks = blocks that can be live on one block-anti-diagonal; picks the smallest (G, S) covering it
+hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st);
+int max_window_blocks();
+hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint32_t* hist, uint32_t nbuckets,
+                       uint32_t* order, hipStream_t st);
+hipError_t launch_pack(const uint8_t* unpacked, uint32_t nbytes, uint32_t* packed, hipStream_t st);
+
+}  // namespace agatha

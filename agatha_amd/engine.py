@@ -1,0 +1,243 @@
+"""ctypes binding of include/agatha_amd.h (the C-ABI of libagatha_amd.so).
+
+Mirrors the reference's host flow for one batch (AGAThA/src/gasal_align.cu:27-273):
+H2D of the unpacked ASCII batch -> pack -> (sort) -> align -> D2H of three int32 result arrays.
+There is deliberately no CPU path here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBNAME = "libagatha_amd.so"
+
+
+class AgathaError(RuntimeError):
+    pass
+
+
+class Scores(C.Structure):
+    """agatha_amd_scores == the reference's gasal_subst_scores (AGAThA/src/gasal.h:165-173)."""
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open", C.c_int32),
+                ("gap_extend", C.c_int32), ("slice_width", C.c_int32), ("z_threshold", C.c_int32),
+                ("band_width", C.c_int32)]
+
+    @classmethod
+    def make(cls, m=2, x=4, q=4, r=2, s=3, z=400, w=751):
+        """Defaults of the reference CLI (args_parser.cpp:12-22)."""
+        return cls(m, x, q, r, s, z, w)
+
+
+def library_path():
+    return os.path.join(_HERE, _LIBNAME)
+
+
+def build_library(force=False):
+    """Compile the HIP library in-tree with hipcc (cross-compiles for gfx950 without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "-s", "clean"])
+    subprocess.check_call(["make", "-C", src, "-s", "all"])
+    return library_path()
+
+
+_lib = None
+
+
+def load_library():
+    """Load libagatha_amd.so; raises AgathaError (never falls back) when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise AgathaError(f"{path} is missing: build it with `make -C agatha_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp, u32p, i32p = C.c_void_p, C.c_void_p, C.c_void_p
+    lib.agatha_amd_strerror.restype = C.c_char_p
+    lib.agatha_amd_strerror.argtypes = [C.c_int]
+    lib.agatha_amd_last_error.restype = C.c_char_p
+    lib.agatha_amd_version.restype = C.c_char_p
+    lib.agatha_amd_device_count.restype = C.c_int
+    lib.agatha_amd_set_device.argtypes = [C.c_int]
+    lib.agatha_amd_max_band.restype = C.c_int
+    lib.agatha_amd_workspace_bytes.restype = C.c_size_t
+    lib.agatha_amd_workspace_bytes.argtypes = [C.c_uint32]
+    lib.agatha_amd_pack.argtypes = [vp, vp, C.c_uint32, u32p]
+    lib.agatha_amd_align.argtypes = [vp, u32p, u32p, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.POINTER(Scores), i32p, i32p, i32p, vp, C.c_size_t]
+    lib.agatha_amd_last_config.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.agatha_amd_last_config.restype = None
+    lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    lib.agatha_amd_free.argtypes = [vp]
+    lib.agatha_amd_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    lib.agatha_amd_host_free.argtypes = [vp]
+    lib.agatha_amd_memcpy_h2d_async.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.agatha_amd_memcpy_d2h_async.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.agatha_amd_stream_create.argtypes = [C.POINTER(vp)]
+    lib.agatha_amd_stream_destroy.argtypes = [vp]
+    lib.agatha_amd_stream_synchronize.argtypes = [vp]
+    lib.agatha_amd_stream_query.argtypes = [vp]
+    lib.agatha_amd_event_create.argtypes = [C.POINTER(vp)]
+    lib.agatha_amd_event_destroy.argtypes = [vp]
+    lib.agatha_amd_event_record.argtypes = [vp, vp]
+    lib.agatha_amd_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+EXPORTS = [
+    "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
+    "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack",
+    "agatha_amd_align", "agatha_amd_last_config", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
+    "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
+    "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
+    "agatha_amd_event_destroy", "agatha_amd_event_record", "agatha_amd_event_elapsed_ms",
+]
+
+
+def _chk(lib, rc):
+    if rc != 0:
+        raise AgathaError(f"{lib.agatha_amd_strerror(rc).decode()} ({rc}): {lib.agatha_amd_last_error().decode()}")
+
+
+class _DevBuf:
+    def __init__(self, lib, nbytes):
+        self.lib, self.nbytes = lib, int(nbytes)
+        p = C.c_void_p()
+        _chk(lib, lib.agatha_amd_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            self.lib.agatha_amd_free(self.ptr)
+            self.ptr = None
+
+
+class DeviceBatch:
+    """One batch resident in HBM: unpacked + packed sequences, the four metadata arrays, the three result
+    arrays and the workspace -- the device half of the reference's gasal_gpu_storage_t (gasal.h:97-155)."""
+
+    def __init__(self, eng, qbuf, tbuf, qoff, toff, qlen, tlen):
+        lib = eng.lib
+        self.eng = eng
+        self.n = int(len(qlen))
+        self.host = [np.ascontiguousarray(qbuf, np.uint8), np.ascontiguousarray(tbuf, np.uint8)] + \
+                    [np.ascontiguousarray(a, np.uint32) for a in (qoff, toff, qlen, tlen)]
+        qb, tb = self.host[0], self.host[1]
+        if qb.size % 8 or tb.size % 8 or qb.size == 0 or tb.size == 0 or self.n == 0:
+            raise AgathaError("batch bytes must be non-zero multiples of 8 and n_alns > 0 "
+                              "(reference gasal_align.cu:33-53)")
+        self.qbytes, self.tbytes = qb.size, tb.size
+        self.max_qlen = int(self.host[4].max())
+        self.max_tlen = int(self.host[5].max())
+        self.d_unp_q = _DevBuf(lib, qb.size + 16)
+        self.d_unp_t = _DevBuf(lib, tb.size + 16)
+        self.d_pk_q = _DevBuf(lib, qb.size // 2 + 16)
+        self.d_pk_t = _DevBuf(lib, tb.size // 2 + 16)
+        self.d_meta = [_DevBuf(lib, 4 * self.n) for _ in range(4)]
+        self.d_res = [_DevBuf(lib, 4 * self.n) for _ in range(3)]
+        self.ws_bytes = lib.agatha_amd_workspace_bytes(self.n)
+        self.d_ws = _DevBuf(lib, self.ws_bytes)
+        self.res_host = np.zeros((3, self.n), np.int32)
+
+    def upload(self, stream=None):
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        bufs = [self.d_unp_q, self.d_unp_t] + self.d_meta
+        for d, h in zip(bufs, self.host):
+            _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, d.ptr, h.ctypes.data, h.nbytes))
+
+    def pack(self, stream=None):
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        _chk(lib, lib.agatha_amd_pack(st, self.d_unp_q.ptr, self.qbytes, self.d_pk_q.ptr))
+        _chk(lib, lib.agatha_amd_pack(st, self.d_unp_t.ptr, self.tbytes, self.d_pk_t.ptr))
+
+    def align(self, scores, stream=None, use_len_hint=True):
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        m = self.d_meta
+        _chk(lib, lib.agatha_amd_align(st, self.d_pk_q.ptr, self.d_pk_t.ptr, m[2].ptr, m[3].ptr, m[0].ptr, m[1].ptr,
+                                       self.n, self.max_qlen if use_len_hint else 0,
+                                       self.max_tlen if use_len_hint else 0, C.byref(scores),
+                                       self.d_res[0].ptr, self.d_res[1].ptr, self.d_res[2].ptr,
+                                       self.d_ws.ptr, self.ws_bytes))
+
+    def download(self, stream=None):
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        for k in range(3):
+            _chk(lib, lib.agatha_amd_memcpy_d2h_async(st, self.res_host[k].ctypes.data, self.d_res[k].ptr, 4 * self.n))
+
+    def packed_host(self):
+        """Copies of the packed device buffers (for the pack-kernel parity test)."""
+        lib = self.eng.lib
+        out = []
+        for d, nb in ((self.d_pk_q, self.qbytes // 2), (self.d_pk_t, self.tbytes // 2)):
+            h = np.zeros(nb // 4, np.uint32)
+            _chk(lib, lib.agatha_amd_memcpy_d2h_async(self.eng.stream, h.ctypes.data, d.ptr, nb))
+            out.append(h)
+        self.eng.synchronize()
+        return out
+
+    def free(self):
+        for b in [self.d_unp_q, self.d_unp_t, self.d_pk_q, self.d_pk_t, self.d_ws] + self.d_meta + self.d_res:
+            b.free()
+
+
+class Engine:
+    """Owns one device + one stream; `align_host_batch` is the whole hot path for one batch."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        if self.lib.agatha_amd_device_count() <= 0:
+            raise AgathaError("no HIP device visible: the alignment path has no CPU fallback")
+        _chk(self.lib, self.lib.agatha_amd_set_device(int(device)))
+        self.device = int(device)
+        s = C.c_void_p()
+        _chk(self.lib, self.lib.agatha_amd_stream_create(C.byref(s)))
+        self.stream = s.value
+
+    def synchronize(self):
+        _chk(self.lib, self.lib.agatha_amd_stream_synchronize(self.stream))
+
+    def last_config(self):
+        g, s = C.c_int(0), C.c_int(0)
+        self.lib.agatha_amd_last_config(C.byref(g), C.byref(s))
+        return g.value, s.value
+
+    def batch(self, qbuf, tbuf, qoff, toff, qlen, tlen):
+        return DeviceBatch(self, qbuf, tbuf, qoff, toff, qlen, tlen)
+
+    def align_host_batch(self, qbuf, tbuf, qoff, toff, qlen, tlen, scores, use_len_hint=True):
+        """ASCII host batch in the GASAL wire format -> (score, query_end, target_end) int32 arrays."""
+        b = self.batch(qbuf, tbuf, qoff, toff, qlen, tlen)
+        try:
+            b.upload(); b.pack(); b.align(scores, use_len_hint=use_len_hint); b.download()
+            self.synchronize()
+            return b.res_host[0].copy(), b.res_host[1].copy(), b.res_host[2].copy()
+        finally:
+            b.free()
+
+    def event(self):
+        e = C.c_void_p()
+        _chk(self.lib, self.lib.agatha_amd_event_create(C.byref(e)))
+        return e.value
+
+    def record(self, ev, stream=None):
+        _chk(self.lib, self.lib.agatha_amd_event_record(ev, stream if stream is not None else self.stream))
+
+    def elapsed_ms(self, e0, e1):
+        ms = C.c_float(0)
+        _chk(self.lib, self.lib.agatha_amd_event_elapsed_ms(e0, e1, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self.stream:
+            self.lib.agatha_amd_stream_destroy(self.stream)
+            self.stream = None

@@ -1,0 +1,101 @@
+/*
+ * agatha_amd.h -- C-ABI of the MI355X guided-alignment engine (libagatha_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of readwrite112/AGAThA: every entry point replaces one
+ * CUDA launch site of the reference's gasal_aln_async() (AGAThA/src/gasal_align.cu).  All pointers
+ * prefixed d_ are DEVICE pointers (HIP), `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Every call is asynchronous on `stream` and allocates nothing.  Return value: 0 on success,
+ * a negative AGATHA_AMD_E* code otherwise (agatha_amd_strerror()).  No torch / C++ types cross this line.
+ *
+ * Data formats are the reference's own:
+ *   unpacked batch : ASCII, each sequence padded with 'N' to a multiple of 8 bytes (host_batch.cpp:79-154)
+ *   packed batch   : 8 bases per uint32, base k of a word in bits 31-4k..28-4k  (pack_rc_seqs.h:21-33)
+ *   offsets        : BYTE offsets into the unpacked batch (multiples of 8); lens: true lengths
+ *   results        : three int32[n]: score, 0-based inclusive end on the query (DP rows) and target (DP columns)
+ */
+#ifndef AGATHA_AMD_H
+#define AGATHA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same seven fields, same order, as the reference's gasal_subst_scores (AGAThA/src/gasal.h:165-173) */
+typedef struct agatha_amd_scores {
+    int32_t match;        /* -m */
+    int32_t mismatch;     /* -x (penalty, positive) */
+    int32_t gap_open;     /* -q */
+    int32_t gap_extend;   /* -r */
+    int32_t slice_width;  /* -s: only decides WHEN z-drop is tested (reference semantics); any value >= 1 */
+    int32_t z_threshold;  /* -z: < 0 disables z-drop */
+    int32_t band_width;   /* -w */
+} agatha_amd_scores;
+
+enum {
+    AGATHA_AMD_OK = 0,
+    AGATHA_AMD_EINVAL = -1,      /* bad argument (NULL pointer, size not a multiple of 8, n == 0 ...) */
+    AGATHA_AMD_EBAND = -2,       /* band wider than the largest compiled window (agatha_amd_max_band()) */
+    AGATHA_AMD_EWORKSPACE = -3,  /* workspace too small, see agatha_amd_workspace_bytes() */
+    AGATHA_AMD_EHIP = -4         /* HIP runtime error, text in agatha_amd_last_error() */
+};
+
+const char* agatha_amd_strerror(int code);
+const char* agatha_amd_last_error(void);     /* thread-local text of the last HIP failure */
+const char* agatha_amd_version(void);
+
+/* device selection: replaces gasal_set_device (interfaces.cpp:86-116) */
+int agatha_amd_device_count(void);
+int agatha_amd_set_device(int device);
+
+/* largest band_width the compiled kernels accept when sequences are longer than the band */
+int agatha_amd_max_band(void);
+
+/* bytes of device scratch agatha_amd_align() needs for up to max_n_alns pairs (replaces the reference's
+ * 0.98 GB/stream global_buffer + pinned host_buffer, ctors.cpp:89-90: this is ~4 B per pair + 64 KiB) */
+size_t agatha_amd_workspace_bytes(uint32_t max_n_alns);
+
+/* ASCII -> packed.  Replaces the gasal_pack_kernel launch (gasal_align.cu:174-185; kernel pack_rc_seqs.h:13-53).
+ * nbytes must be a multiple of 8; d_unpacked 16-byte aligned; d_packed holds nbytes/8 words. */
+int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, uint32_t* d_packed);
+
+/* Sort + align one batch.  Replaces agatha_kernel_launcher (gasal_align.cu:10-23): the agatha_sort kernel,
+ * its D2H / host std::sort / H2D round trip, and agatha_kernel itself.
+ * max_query_len / max_target_len: upper bounds of the lengths in this batch (0 = unknown); they only let
+ * short batches run on a narrower lane group and never change results. */
+int agatha_amd_align(void* stream,
+                     const uint32_t* d_packed_query, const uint32_t* d_packed_target,
+                     const uint32_t* d_query_lens, const uint32_t* d_target_lens,
+                     const uint32_t* d_query_offsets, const uint32_t* d_target_offsets,
+                     uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
+                     const agatha_amd_scores* scores,
+                     int32_t* d_aln_score, int32_t* d_query_batch_end, int32_t* d_target_batch_end,
+                     void* d_workspace, size_t workspace_bytes);
+
+/* lane-group shape the last agatha_amd_align() of this thread used (diagnostics for bench.py / DESIGN.md) */
+void agatha_amd_last_config(int* lanes_per_pair, int* slots_per_lane);
+
+/* Thin device-memory helpers so that non-HIP hosts (ctypes, cgo, JNI) can drive the library without
+ * linking the HIP runtime themselves.  Synchronous except the *_async copies. */
+int agatha_amd_malloc(void** d_ptr, size_t bytes);
+int agatha_amd_free(void* d_ptr);
+int agatha_amd_host_alloc(void** h_ptr, size_t bytes);   /* pinned */
+int agatha_amd_host_free(void* h_ptr);
+int agatha_amd_memcpy_h2d_async(void* stream, void* d_dst, const void* h_src, size_t bytes);
+int agatha_amd_memcpy_d2h_async(void* stream, void* h_dst, const void* d_src, size_t bytes);
+int agatha_amd_stream_create(void** stream);
+int agatha_amd_stream_destroy(void* stream);
+int agatha_amd_stream_synchronize(void* stream);
+int agatha_amd_stream_query(void* stream);               /* 0 = idle, 1 = busy, <0 = error */
+/* timing on the launch stream (the reference's -p mode, gasal_align.cu:219-236, done per stream) */
+int agatha_amd_event_create(void** event);
+int agatha_amd_event_destroy(void* event);
+int agatha_amd_event_record(void* event, void* stream);
+int agatha_amd_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGATHA_AMD_H */

@@ -26,8 +26,8 @@ def make_params(m=2, x=4, q=4, r=2, s=3, z=400, w=751):
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB) or \
-            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "agatha_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("agatha_oracle.c", "agatha_lanes_model.c", "Makefile")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     return _LIB
 
@@ -45,6 +45,9 @@ def lib():
         _lib.agatha_oracle_pack.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.agatha_nominal_cells.argtypes = [C.c_int, C.c_int, C.c_int]
         _lib.agatha_nominal_cells.restype = C.c_int64
+        _lib.agatha_lanes_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int,
+                                                               C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        _lib.agatha_lanes_batch.restype = None
     return _lib
 
 
@@ -75,6 +78,22 @@ def align_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, wide=False, model=MO
     lib().agatha_oracle_batch(qbuf.ctypes.data, tbuf.ctypes.data, *[a.ctypes.data for a in arrs], n,
                               C.byref(params), int(wide), int(model), int(threads),
                               out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data)
+    return out[0], out[1], out[2]
+
+
+def lanes_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, G, S, threads=1):
+    """CPU emulation of the HIP kernel's lane/slot schedule (oracle/agatha_lanes_model.c)."""
+    n = len(qlen)
+    qbuf = np.ascontiguousarray(qbuf, np.uint8)
+    tbuf = np.ascontiguousarray(tbuf, np.uint8)
+    arrs = [np.ascontiguousarray(a, np.uint32) for a in (qoff, toff, qlen, tlen)]
+    out = np.zeros((3, n), np.int32)
+    rc = C.c_int(0)
+    lib().agatha_lanes_batch(qbuf.ctypes.data, tbuf.ctypes.data, *[a.ctypes.data for a in arrs], n,
+                             C.byref(params), int(G), int(S), int(threads),
+                             out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, C.byref(rc))
+    if rc.value:
+        raise ValueError("G*S too small for this band")
     return out[0], out[1], out[2]
 
 

@@ -1,0 +1,99 @@
+"""GPU parity: the HIP path (through the C-ABI of libagatha_amd.so) against the oracle and the golden vectors.
+Everything here needs a real MI355X: run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O, synth
+from helpers import load_kats, load_ref_vectors
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import agatha_amd
+    e = agatha_amd.Engine(0)        # raises if the HIP library or the GPU is missing: no fallback
+    yield e
+    e.close()
+
+
+def _scores(p):
+    import agatha_amd
+    return agatha_amd.Scores.make(**p)
+
+
+def _gpu(eng, qs, ts, p, **kw):
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    return eng.align_host_batch(qb, tb, qo, to, ql, tl, _scores(p), **kw)
+
+
+def test_pack_matches_reference_layout(eng):
+    rng = np.random.default_rng(0)
+    seqs = [bytes(rng.choice(list(b"ACGTNacgtn"), size=int(n))) for n in (1, 7, 8, 9, 63, 1000, 4097)]
+    qb, qo, ql = O.make_batch(seqs)
+    tb, to, tl = O.make_batch(seqs[::-1])
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    b.upload(); b.pack()
+    pq, pt = b.packed_host()
+    b.free()
+    assert (pq == O.pack(qb)).all() and (pt == O.pack(tb)).all()
+
+
+def test_appendix_e_kats(eng):
+    doc = load_kats()
+    for c in doc["cases"]:
+        s, q, t = _gpu(eng, [c["query"]], [c["target"]], c["params"])
+        assert [int(s[0]), int(q[0]), int(t[0])] == c["expect"], (c["id"], c["params"], c["note"])
+
+
+def test_wide_semantics_beyond_int16(eng):
+    """Outside the reference's 16-bit domain the engine keeps int32 arithmetic: Appendix E #14."""
+    sat = load_kats()["saturation"]
+    rng = np.random.default_rng(sat["seed"])
+    seq = "".join(rng.choice(list("ACGT"), sat["length"]))
+    s, q, t = _gpu(eng, [seq], [seq], dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751))
+    assert [int(s[0]), int(q[0]), int(t[0])] == sat["expect_wide"]
+
+
+@pytest.mark.parametrize("g", load_ref_vectors(), ids=lambda g: g["name"])
+def test_reference_vectors(eng, g):
+    """Bit-exact against outputs of the reference kernel (tests/golden/gen_golden.py)."""
+    s, q, t = eng.align_host_batch(g["qbatch"], g["tbatch"], g["qoff"], g["toff"], g["qlen"], g["tlen"],
+                                   _scores(g["params"]))
+    exp = g["expect"]
+    bad = np.nonzero((s != exp[0]) | (q != exp[1]) | (t != exp[2]))[0]
+    assert bad.size == 0, (g["name"], bad[:8], s[bad[:8]], exp[0][bad[:8]])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_batches_vs_oracle(eng, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(6):
+        w = int(rng.choice([0, 1, 5, 8, 9, 16, 17, 33, 64, 100, 248, 500, 751, 1500]))
+        p = dict(m=int(rng.choice([1, 2, 3])), x=int(rng.choice([2, 4, 5])), q=int(rng.choice([2, 4, 6])),
+                 r=int(rng.choice([1, 2])), s=int(rng.choice([1, 2, 3, 5, 7])),
+                 z=int(rng.choice([-1, 0, 20, 100, 400])), w=w)
+        e = float(rng.uniform(0, 0.15))
+        n = int(rng.choice([1, 3, 17, 64, 200]))
+        maxlen = int(rng.choice([60, 500, 4000]))
+        qs, ts = synth.make_pairs(int(rng.integers(1 << 30)), n, lambda r: int(np.exp(r.uniform(0, np.log(maxlen)))),
+                                  e, e, e, n_rate=0.01 if rng.random() < 0.3 else 0.0)
+        if rng.random() < 0.3:
+            ts = [t[: max(1, len(t) // int(rng.integers(2, 5)))] for t in ts]
+        qb, qo, ql = O.make_batch(qs)
+        tb, to, tl = O.make_batch(ts)
+        exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=4)
+        for hint in (True, False):          # with / without the length hint: different lane-group shapes
+            got = eng.align_host_batch(qb, tb, qo, to, ql, tl, _scores(p), use_len_hint=hint)
+            for a, b_ in zip(got, exp):
+                assert (a == b_).all(), (p, hint, eng.last_config())
+
+
+def test_rejects_bad_arguments(eng):
+    import agatha_amd
+    qb, qo, ql = O.make_batch([b"ACGT"])
+    with pytest.raises(agatha_amd.AgathaError):
+        eng.align_host_batch(qb, qb, qo, qo, ql, ql, _scores(dict(w=10 ** 6)))       # band beyond the compiled window
+    with pytest.raises(agatha_amd.AgathaError):
+        eng.align_host_batch(qb[:4], qb, qo, qo, ql, ql, _scores({}))                 # bytes not a multiple of 8
