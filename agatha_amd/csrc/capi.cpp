@@ -10,6 +10,7 @@ namespace {
 
 thread_local char g_err[256] = "";
 thread_local int g_lastG = 0, g_lastS = 0;
+thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 
 int hip_fail(hipError_t e, const char* what)
 {
@@ -113,9 +114,13 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.score = d_aln_score; L.qend = d_query_batch_end; L.tend = d_target_batch_end;
     L.p = {sc->match, sc->mismatch, sc->gap_open, sc->gap_extend, sc->slice_width, sc->z_threshold, sc->band_width};
     L.num_cus = num_cus();
+    if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));
     HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st));
+    if (g_ev1) HIPCHK(hipEventRecord(g_ev1, st));
     return 0;
 }
+
+void agatha_amd_set_kernel_events(void* ev_begin, void* ev_end) { g_ev0 = (hipEvent_t)ev_begin; g_ev1 = (hipEvent_t)ev_end; }
 
 void agatha_amd_last_config(int* G, int* S) { if (G) *G = g_lastG; if (S) *S = g_lastS; }
 

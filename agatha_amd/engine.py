@@ -69,6 +69,8 @@ def load_library():
     lib.agatha_amd_pack.argtypes = [vp, vp, C.c_uint32, u32p]
     lib.agatha_amd_align.argtypes = [vp, u32p, u32p, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.POINTER(Scores), i32p, i32p, i32p, vp, C.c_size_t]
+    lib.agatha_amd_set_kernel_events.argtypes = [vp, vp]
+    lib.agatha_amd_set_kernel_events.restype = None
     lib.agatha_amd_last_config.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.agatha_amd_last_config.restype = None
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -92,7 +94,7 @@ def load_library():
 EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack",
-    "agatha_amd_align", "agatha_amd_last_config", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_align", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -113,9 +115,9 @@ class _DevBuf:
         self.ptr = p.value
 
     def free(self):
-        if self.ptr:
+        if self.ptr and not getattr(self, "external", False):
             self.lib.agatha_amd_free(self.ptr)
-            self.ptr = None
+        self.ptr = None
 
 
 class DeviceBatch:
@@ -144,6 +146,16 @@ class DeviceBatch:
         self.ws_bytes = lib.agatha_amd_workspace_bytes(self.n)
         self.d_ws = _DevBuf(lib, self.ws_bytes)
         self.res_host = np.zeros((3, self.n), np.int32)
+
+    def use_result_pointers(self, ptrs):
+        """Write results into caller-owned device arrays (e.g. torch tensors used for the RCCL gather)."""
+        for b in self.d_res:
+            b.free()
+        self.d_res = []
+        for p in ptrs:
+            d = _DevBuf.__new__(_DevBuf)
+            d.lib, d.nbytes, d.ptr, d.external = self.eng.lib, 4 * self.n, int(p), True
+            self.d_res.append(d)
 
     def upload(self, stream=None):
         lib = self.eng.lib
@@ -231,6 +243,9 @@ class Engine:
 
     def record(self, ev, stream=None):
         _chk(self.lib, self.lib.agatha_amd_event_record(ev, stream if stream is not None else self.stream))
+
+    def set_kernel_events(self, e0, e1):
+        self.lib.agatha_amd_set_kernel_events(e0, e1)
 
     def elapsed_ms(self, e0, e1):
         ms = C.c_float(0)

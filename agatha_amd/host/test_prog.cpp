@@ -1,0 +1,154 @@
+// test_prog.cpp -> `manual`: the AGAThA command line on the MI355X engine.
+//
+// Caller contract of the reference's AGAThA/test_prog/test_prog.cpp:21-410: two FASTA files with the same
+// number of records (record k of file 1 = DP rows / "query_batch", record k of file 2 = DP columns /
+// "target_batch"), header character > < / + = op code 0..3, sequence lines concatenated; pairs are cut into
+// batches of -a alignments, each batch goes through gasal_host_batch_fill + gasal_aln_async on one of
+// NB_STREAMS storages per host thread; with -p every pair prints
+//     <score>\tquery_batch_end=<q>\ttarget_batch_end=<t>
+// in input order within a batch, and one kernel-milliseconds line per batch is appended to the raw log.
+// Own reader (each file is parsed on its own, so records with different line counts stay in step).
+#include "../../include/gasal_header.h"
+
+#include <math.h>
+#include <omp.h>
+
+#include <vector>
+
+#define NB_STREAMS 2
+
+extern "C" float agatha_gasal_last_batch_ms(gasal_gpu_storage_t* s);
+
+struct FastaSet {
+    std::vector<std::string> seqs;
+    std::vector<uint8_t> ops;
+};
+
+static void read_fasta(std::ifstream& in, FastaSet& out)
+{
+    static const char line_starts[] = "></+";      // op = index: forward, reverse, complement, reverse-complement
+    std::string line;
+    bool open_record = false;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        const char* hit = strchr(line_starts, line[0]);
+        if (hit && *hit) {
+            out.ops.push_back((uint8_t)(hit - line_starts));
+            out.seqs.emplace_back();
+            open_record = true;
+        } else if (open_record) {
+            out.seqs.back() += line;
+        } else {
+            std::cerr << "Batch1 and target_batch files should be fasta having same number of sequences" << std::endl;
+            exit(EXIT_FAILURE);
+        }
+    }
+}
+
+int main(int argc, char** argv)
+{
+    Parameters* args = new Parameters(argc, argv);
+    args->parse();
+    const int print_out = args->print_out;
+    const int n_threads = args->n_threads > 0 ? args->n_threads : 1;
+
+    gasal_subst_scores sub_scores;
+    sub_scores.match = args->sa;
+    sub_scores.mismatch = args->sb;
+    sub_scores.gap_open = args->gapo;
+    sub_scores.gap_extend = args->gape;
+    sub_scores.slice_width = args->slice_width;
+    sub_scores.z_threshold = args->z_threshold;
+    sub_scores.band_width = args->band_width;
+    gasal_copy_subst_scores(&sub_scores);
+
+    FastaSet Qs, Ts;
+    read_fasta(args->query_batch_fasta, Qs);
+    read_fasta(args->target_batch_fasta, Ts);
+    if (Qs.seqs.size() != Ts.seqs.size() || Qs.seqs.empty()) {
+        std::cerr << "Batch1 and target_batch files should be fasta having same number of sequences" << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    const int total_seqs = (int)Qs.seqs.size();
+    uint32_t max_q = 0, max_t = 0;
+    for (int i = 0; i < total_seqs; i++) {
+        max_q = std::max<uint32_t>(max_q, (uint32_t)Qs.seqs[i].size());
+        max_t = std::max<uint32_t>(max_t, (uint32_t)Ts.seqs[i].size());
+    }
+    const uint32_t maximum_sequence_length = std::max(max_q, max_t);
+
+    // equal split of the pairs over the host threads (test_prog.cpp:195-203)
+    std::vector<int> thread_first(n_threads), thread_count(n_threads);
+    const int per_thread = (int)ceil((double)total_seqs / n_threads);
+    for (int t = 0, done = 0; t < n_threads; t++) {
+        thread_first[t] = done;
+        thread_count[t] = std::max(0, std::min(per_thread, total_seqs - done));
+        done += thread_count[t];
+    }
+
+    omp_set_num_threads(n_threads);
+    std::vector<gasal_gpu_storage_v> vecs(n_threads);
+    for (int t = 0; t < n_threads; t++) {
+        vecs[t] = gasal_init_gpu_storage_v(NB_STREAMS);
+        gasal_init_streams(&vecs[t], (int)max_q + 7, (int)max_t + 7, (int32_t)maximum_sequence_length, args);
+    }
+
+#pragma omp parallel
+    {
+        const int tid = omp_get_thread_num();
+        const int n_seqs = thread_count[tid];
+        const int n_batches = (int)ceil((double)n_seqs / args->kernel_align_num);
+        int next = thread_first[tid], seqs_done = 0, batches_done = 0;
+        struct Slot { gasal_gpu_storage_t* st; int n; } slot[NB_STREAMS];
+        for (int z = 0; z < NB_STREAMS; z++) { slot[z].st = &vecs[tid].a[z]; slot[z].n = 0; }
+
+        while (batches_done < n_batches) {
+            int z = 0;
+            while (z < NB_STREAMS && slot[z].st->is_free != 1) z++;
+            if (seqs_done < n_seqs && z < NB_STREAMS) {
+                gasal_gpu_storage_t* st = slot[z].st;
+                uint32_t qidx = 0, tidx = 0;
+                int j = 0;
+                const int first = next;
+                for (; seqs_done < n_seqs && j < args->kernel_align_num; j++, seqs_done++, next++) {
+                    st->current_n_alns++;
+                    if (st->current_n_alns > st->host_max_n_alns) gasal_host_alns_resize(st, st->host_max_n_alns * 2, args);
+                    st->host_query_batch_offsets[j] = qidx;
+                    st->host_target_batch_offsets[j] = tidx;
+                    qidx = gasal_host_batch_fill(st, qidx, Qs.seqs[next].c_str(), (uint32_t)Qs.seqs[next].size(), QUERY);
+                    tidx = gasal_host_batch_fill(st, tidx, Ts.seqs[next].c_str(), (uint32_t)Ts.seqs[next].size(), TARGET);
+                    st->host_query_batch_lens[j] = (uint32_t)Qs.seqs[next].size();
+                    st->host_target_batch_lens[j] = (uint32_t)Ts.seqs[next].size();
+                }
+                gasal_op_fill(st, Qs.ops.data() + first, (uint32_t)j, QUERY);
+                gasal_op_fill(st, Ts.ops.data() + first, (uint32_t)j, TARGET);
+                slot[z].n = j;
+                gasal_aln_async(st, qidx, tidx, (uint32_t)j, args);
+                st->current_n_alns = 0;
+            }
+            for (z = 0; z < NB_STREAMS; z++) {
+                if (gasal_is_aln_async_done(slot[z].st) == 0) {
+                    if (print_out) {
+#pragma omp critical
+                        {
+                            const gasal_res_t* r = slot[z].st->host_res;
+                            for (int j = 0; j < slot[z].n; j++)
+                                std::cout << r->aln_score[j] << "\tquery_batch_end=" << r->query_batch_end[j]
+                                          << "\ttarget_batch_end=" << r->target_batch_end[j] << std::endl;
+                            if (args->raw_file.is_open()) args->raw_file << agatha_gasal_last_batch_ms(slot[z].st) << std::endl;
+                        }
+                    }
+                    batches_done++;
+                }
+            }
+        }
+    }
+
+    for (int t = 0; t < n_threads; t++) {
+        gasal_destroy_streams(&vecs[t], args);
+        gasal_destroy_gpu_storage_v(&vecs[t]);
+    }
+    delete args;
+    return 0;
+}

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the guided-alignment hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch that is already resident in HBM as unpacked ASCII
+(the state right after the H2D copy in the reference's gasal_aln_async): pack -> length sort -> align ->
+D2H of the three result arrays (+ for N > 1 an RCCL all-gather of the results, the only collective).
+Workload = BASELINE.json configs[1]: 10 k synthetic ONT-like pairs, ~10 kb, band 751, z-drop 400, m2 x4 q4 r2,
+per GPU (weak scaling: every rank aligns its own 10 k pairs).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md)
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
+OPS_PER_CELL = 11                     # algorithmic int32 ops of one DP cell incl. the anti-diagonal maximum
+
+
+def algorithmic_bytes(qlen, tlen):
+    """Must-move HBM bytes of the align kernel: packed inputs once + lens/offsets + results."""
+    q = (np.asarray(qlen, np.int64) + 7) // 8
+    t = (np.asarray(tlen, np.int64) + 7) // 8
+    return int((4 * q + 4 * t + 28).sum())
+
+
+def cpu_baseline(O, qb, tb, qo, to, ql, tl, params, w, budget_s=12.0):
+    """The oracle (a scalar C port of the reference recurrence) on a bounded sample, OpenMP over pairs."""
+    cores = os.cpu_count() or 1
+    n = len(ql)
+    k0 = min(n, 2 * cores)
+    t0 = time.time()
+    O.align_batch(qb, tb, qo[:k0], to[:k0], ql[:k0], tl[:k0], params, wide=True, model=O.MODEL_SLICES, threads=cores)
+    dt0 = max(time.time() - t0, 1e-3)
+    k = int(min(n, max(k0, k0 * budget_s / dt0)))
+    t0 = time.time()
+    O.align_batch(qb, tb, qo[:k], to[:k], ql[:k], tl[:k], params, wide=True, model=O.MODEL_SLICES, threads=cores)
+    dt = time.time() - t0
+    cells = O.nominal_cells_np(ql[:k], tl[:k], w)
+    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": f"first {k} pairs of the same batch, {dt:.1f} s, scalar C oracle (oracle/agatha_oracle.c) "
+                      f"with OpenMP schedule(dynamic) over pairs",
+            "pairs_per_s": k / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=10000, help="pairs per GPU (BASELINE config: 10000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = "WORLD_SIZE" in os.environ
+    torch = dist = None
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
+
+    import agatha_amd
+    from oracle import oracle as O, synth        # generators + the cpu_baseline leg only
+
+    eng = agatha_amd.Engine(local_rank)
+    stream = None
+    if use_dist:
+        stream = torch.cuda.current_stream().cuda_stream   # run on torch's stream so the gather is ordered behind align
+    W_BAND, Z = 751, 400
+    scores = agatha_amd.Scores.make(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND)
+
+    qs, ts = synth.cfg_c1(n=a.pairs, seed=0xA6A70001 + rank)
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    del qs, ts
+    cells = O.nominal_cells_np(ql, tl, W_BAND)
+    abytes = algorithmic_bytes(ql, tl)
+
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    res_t = gathered = None
+    if use_dist:
+        res_t = torch.empty((3, b.n), dtype=torch.int32, device="cuda")
+        gathered = torch.empty((world, 3, b.n), dtype=torch.int32, device="cuda")
+        b.use_result_pointers([res_t[k].data_ptr() for k in range(3)])
+    b.upload(stream)
+    eng.synchronize() if stream is None else torch.cuda.synchronize()
+
+    kev = [(eng.event(), eng.event()) for _ in range(a.steps)]
+
+    def step(i=None):
+        if i is not None:
+            eng.set_kernel_events(*kev[i])
+        b.pack(stream)
+        b.align(scores, stream)
+        if i is not None:
+            eng.set_kernel_events(None, None)
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, res_t)       # RCCL: 12 B per pair, the only exchange
+        else:
+            b.download(stream)
+
+    def sync():
+        if use_dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+        else:
+            eng.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tc = torch.tensor([float(cells), float(b.n)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+        total_cells, total_pairs = float(tc[0].item()), float(tc[1].item())
+    else:
+        total_cells, total_pairs = float(cells), float(b.n)
+
+    kms = [eng.elapsed_ms(e0, e1) for e0, e1 in kev] if a.steps else [float("nan")]
+    kernel_ms = float(np.mean(kms))
+    G, S = eng.last_config()
+
+    if rank == 0:
+        ms_per_step = elapsed / max(a.steps, 1) * 1e3
+        out = {
+            "metric": "GCUPS (banded DP cells/s), 10 kb ONT pairs, band=751, z=400",
+            "value": total_cells * a.steps / elapsed / 1e9,
+            "unit": "GCUPS",
+            "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": f"C1: {a.pairs} synthetic ONT-like pairs per GPU, ~10 kb (8-12 kb), "
+                                   f"sub 3% ins 3% del 4%, m2 x4 q4 r2 w751 z400 s3 (BASELINE.json configs[1])",
+                       "pairs_per_gpu": a.pairs, "lanes_per_pair": G, "slots_per_lane": S,
+                       "step": "pack + sort + align + D2H results" + (" + RCCL all-gather" if use_dist else "")},
+            "pairs_per_s": total_pairs * a.steps / elapsed,
+            "kernel_ms": kernel_ms,
+            "kernel_gcups_rank0": cells / kernel_ms / 1e6,
+            "roofline": {"bound": "hbm", "achieved": abytes / kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": abytes / kernel_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": f"agatha::align_kernel<{G},{S}>",
+                         "note": "integer max/add DP at ~1400 cells per algorithmic byte: the HBM roof is not binding, "
+                                 "see roofline_valu (DESIGN.md, SURVEY.md 8(d))"},
+            "roofline_valu": {"bound": "valu-int32", "achieved": cells * OPS_PER_CELL / kernel_ms / 1e9,
+                              "peak": VALU_PEAK_TOPS, "unit": "Tops/s",
+                              "frac": cells * OPS_PER_CELL / kernel_ms / 1e9 / VALU_PEAK_TOPS,
+                              "ops_per_cell": OPS_PER_CELL},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(O, qb, tb, qo, to, ql, tl,
+                                               O.make_params(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND), W_BAND)
+        print(json.dumps(out))
+    b.free()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,11 @@ int agatha_amd_align(void* stream,
                      int32_t* d_aln_score, int32_t* d_query_batch_end, int32_t* d_target_batch_end,
                      void* d_workspace, size_t workspace_bytes);
 
+/* Optional: a hipEvent_t pair (as void*) that the NEXT agatha_amd_align() calls of this thread record directly
+ * around the alignment kernel launch (excluding the sort); pass NULLs to switch it off.  Used by bench.py for
+ * the per-kernel duration of the roofline line. */
+void agatha_amd_set_kernel_events(void* ev_begin, void* ev_end);
+
 /* lane-group shape the last agatha_amd_align() of this thread used (diagnostics for bench.py / DESIGN.md) */
 void agatha_amd_last_config(int* lanes_per_pair, int* slots_per_lane);
 

@@ -1,0 +1,2 @@
+/* Forwarding stub: the reference splits its host API over AGAThA/src/args_parser.h and friends; here it is one header. */
+#include "gasal_header.h"

@@ -93,7 +93,11 @@ def test_random_batches_vs_oracle(eng, seed):
 def test_rejects_bad_arguments(eng):
     import agatha_amd
     qb, qo, ql = O.make_batch([b"ACGT"])
+    # a huge band is fine while the sequences are short (window = min(W+1, ceil(Q/8), ceil(R/8)))...
+    s, q, t = eng.align_host_batch(qb, qb, qo, qo, ql, ql, _scores(dict(w=10 ** 6)))
+    assert (int(s[0]), int(q[0]), int(t[0])) == (8, 3, 3)
+    # ...and refused, loudly, once nothing bounds the window below what is compiled
     with pytest.raises(agatha_amd.AgathaError):
-        eng.align_host_batch(qb, qb, qo, qo, ql, ql, _scores(dict(w=10 ** 6)))       # band beyond the compiled window
+        eng.align_host_batch(qb, qb, qo, qo, ql, ql, _scores(dict(w=10 ** 6)), use_len_hint=False)
     with pytest.raises(agatha_amd.AgathaError):
         eng.align_host_batch(qb[:4], qb, qo, qo, ql, ql, _scores({}))                 # bytes not a multiple of 8
