@@ -43,10 +43,10 @@ template <int G>
 __device__ __forceinline__ int group_max(int v, int lane)
 {
     // rotations inside a 16-lane DPP row: row_ror:1,2,4,8
-    v = imax(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));
-    v = imax(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));
-    v = imax(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));
-    v = imax(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
+    v = imax(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x121, 0xf, 0xf, true));
+    v = imax(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x122, 0xf, 0xf, true));
+    v = imax(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x124, 0xf, 0xf, true));
+    v = imax(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x128, 0xf, 0xf, true));
     if (G >= 32) v = imax(v, lane_read(v, lane ^ 16));
     if (G >= 64) v = imax(v, lane_read(v, lane ^ 32));
     return v;
@@ -81,11 +81,12 @@ __device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge,
 //   oh      H(row, last column) out
 // MASKED: per-cell band test of boundary blocks and the row limit of the last row block, as EXEC masks
 //         built once per block (km: one lane mask per cell diagonal jl-il, rm: one per row).
-// HAS_N : either word holds an N (score -1, gasal_kernels.h:48-50); otherwise the N test is dropped.
-template <bool MASKED, bool HAS_N, int K>
+// any_n : wave-uniform: some lane's words hold an N (score -1, gasal_kernels.h:48-50); patched per row, rarely.
+template <bool MASKED, int K>
 __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, const int (&rh)[8], int (&e)[8],
                                          int (&oh)[8], int (&A)[15], uint32_t qword, uint32_t rword,
-                                         int va, int vnb, int gapoe, int ge, int crel0, int nrows, int tu, int tl)
+                                         int va, int vnb, int gapoe, int ge, int crel0, int nrows, int tu, int tl,
+                                         bool any_n)
 {
     uint32_t rb[8];
     int cj[8];
@@ -105,10 +106,16 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
             int t[8];
 #pragma unroll
             for (int jl = 0; jl < 8; jl++) {
-                int sc = (qb == rb[jl]) ? va : vnb;
-                if (HAS_N) sc = (qb == N_VALUE || rb[jl] == N_VALUE) ? -1 : sc;
+                const int sc = (qb == rb[jl]) ? va : vnb;
                 const int d = (jl == 0) ? ((il == 0) ? corner : rh[il - 1]) : h[jl - 1];
                 t[jl] = sc + d;
+            }
+            if (any_n) {      // wave-uniform and rare: some lane's words hold an N (score -1, gasal_kernels.h:48-50)
+#pragma unroll
+                for (int jl = 0; jl < 8; jl++) {
+                    const int d = (jl == 0) ? ((il == 0) ? corner : rh[il - 1]) : h[jl - 1];
+                    if (qb == N_VALUE || rb[jl] == N_VALUE) t[jl] = d - 1;
+                }
             }
             // every diagonal term is taken from the PREVIOUS row's H: pin them before H is overwritten
 #pragma unroll
@@ -126,9 +133,11 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
                 }
             }
             oh[il] = h[7]; e[il] = ev;
-            corner = rh[il];                       // p[1] = h[0] of the last processed row (agatha_kernel.h:28)
         }
     }
+    // p[1] = h[0] of the last processed row (agatha_kernel.h:28).  A block with fewer than 8 rows is the last
+    // block of its column (q == pql-1), after which the corner is never read again, so row 7 is always right.
+    corner = rh[7];
 }
 
 __device__ __forceinline__ bool word_has_n(uint32_t v)
@@ -254,21 +263,31 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
                 }
                 const bool left_ok = (xr[s] == r - 1);
                 int rh[8];
+                if (__any(!left_ok && 8 * q <= w)) {
+                    // a row block starts inside the first w rows: its left boundary holds real gap scores
 #pragma unroll
-                for (int il = 0; il < 8; il++) {
-                    const int row = 8 * q + il;
-                    const int kk = -(gapoe + ge * row);
-                    const int ih = (row <= w) ? kk : NEG_INF2;            // H(row, -1)   (agatha_kernel.h:126-131)
-                    const int ie = (row <= w) ? kk - gapoe : NEG_INF2;    // E(row, 0)
-                    rh[il] = left_ok ? xh[s][il] : ih;
-                    xe[s + 1][il] = left_ok ? xe[s][il] : ie;             // E travels in place through the block
+                    for (int il = 0; il < 8; il++) {
+                        const int row = 8 * q + il;
+                        const int kk = -(gapoe + ge * row);
+                        const int ih = (row <= w) ? kk : NEG_INF2;            // H(row, -1)   (agatha_kernel.h:126-131)
+                        const int ie = (row <= w) ? kk - gapoe : NEG_INF2;    // E(row, 0)
+                        rh[il] = left_ok ? xh[s][il] : ih;
+                        xe[s + 1][il] = left_ok ? xe[s][il] : ie;             // E travels in place through the block
+                    }
+                } else {
+#pragma unroll
+                    for (int il = 0; il < 8; il++) {
+                        rh[il] = left_ok ? xh[s][il] : NEG_INF2;
+                        xe[s + 1][il] = left_ok ? xe[s][il] : NEG_INF2;
+                    }
                 }
                 const int tu = boundary ? w + 8 * q - 8 * r : 1000;     // cell skipped when jl - il > tu (:33)
                 const int tl = boundary ? w - 8 * q + 8 * r : 1000;     //                or il - jl > tl
                 const int crel0 = 8 * r - cb;
-                // one generic variant: edge blocks (band test) exist on every anti-diagonal, so a mask-free
-                // variant would rarely run for a whole wave and only costs instruction-cache space
-                block8x8<true, true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, va, vnb, gapoe, ge, crel0, nrows, tu, tl);
+                // Edge blocks (band test) exist on every anti-diagonal, so a mask-free variant would rarely run for
+                // a whole wave; Ns are rare (padding of the last column block, occasional N in a read).
+                const bool any_n = __any(word_has_n(qword) || word_has_n(rw));
+                block8x8<true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, va, vnb, gapoe, ge, crel0, nrows, tu, tl, any_n);
             }
         }
         // X[S] of the left neighbour lane becomes X[0]

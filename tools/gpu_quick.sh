@@ -1,0 +1,20 @@
+# quick GPU check: parity tests + bench + one PMC pass (instruction counts)
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+TAG=${1:-q}
+timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_$TAG.log
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc_$TAG -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/pmc_$TAG.err
+tail -2 gpurun_out/pytest_gpu_$TAG.log
+python3 - <<PY
+import json,csv,glob,collections
+b=json.load(open("gpurun_out/bench_$TAG.json")); print("GCUPS",round(b["value"],1),"kernel_ms",round(b["kernel_ms"],2),"cfg",b["config"]["lanes_per_pair"],b["config"]["slots_per_lane"])
+agg=collections.defaultdict(list)
+for f in glob.glob("gpurun_out/pmc_$TAG/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "align_kernel" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+m={k:sum(v)/len(v) for k,v in agg.items()}
+cells=1.437e11
+print({k:"%.3e"%v for k,v in m.items()})
+if "SQ_INSTS_VALU" in m: print("VALU lane-ops/cell %.2f"%(m["SQ_INSTS_VALU"]*64/cells), "SALU/VALU %.2f"%(m["SQ_INSTS_SALU"]/m["SQ_INSTS_VALU"]))
+PY
