@@ -28,7 +28,7 @@
 
 namespace agatha {
 
-#define NEG_INF2 (-16384)   // SHRT_MIN/2: the reference's -infinity (gasal_kernels.h:39)
+#define NEG_INF2 (-16384)   // SHRT_MIN/2: the reference's -infinity (gasal_kernels.h:39); kernels use NEG_INF2 << K
 #define N_VALUE 14u         // 'N' & 0xF (AGAThA/Makefile:4)
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -58,18 +58,19 @@ template <int GS> struct KeyBits {          // smallest K with 2^K >= 8 * (GS + 
 };
 
 // initial column state of column block r: H(-1, c), F(0, c)  (agatha_kernel.h:133-148, 207-215)
-__device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge, int (&h)[8], int (&f)[8], int& corner)
+// gapoe, ge and neg are already in the shifted score domain.
+__device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge, int neg, int (&h)[8], int (&f)[8], int& corner)
 {
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         const int c = 8 * r + m;
         const int k = -(gapoe + ge * c);
         const bool in = (c < R) && (c <= w);
-        h[m] = in ? k : NEG_INF2;
-        f[m] = in ? k - gapoe : NEG_INF2;
+        h[m] = in ? k : neg;
+        f[m] = in ? k - gapoe : neg;
     }
     const int kc = -(gapoe + ge * (8 * r - 1));
-    corner = (r == 0) ? 0 : ((8 * r - 1) <= w ? kc : NEG_INF2);
+    corner = (r == 0) ? 0 : ((8 * r - 1) <= w ? kc : neg);
 }
 
 // One 8x8 block (q, r): the reference's CORE_COMPUTE / CORE_COMPUTE_BOUNDARY sweep
@@ -79,6 +80,8 @@ __device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge,
 //   rh      H(row, column left of the block) for the 8 rows                    (in)
 //   e       E(row, first column) in, E(row, column right of the block) out     (in/out)
 //   oh      H(row, last column) out
+// All scores are carried pre-shifted (H << K, and so are match/mismatch/gap constants): max/add commute with the
+// scaling, and the packed anti-diagonal key (H << K) + relative column then costs a single three-operand add.
 // MASKED: per-cell band test of boundary blocks and the row limit of the last row block, as EXEC masks
 //         built once per block (km: one lane mask per cell diagonal jl-il, rm: one per row).
 // any_n : wave-uniform: some lane's words hold an N (score -1, gasal_kernels.h:48-50); patched per row, rarely.
@@ -89,13 +92,14 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
                                          bool any_n)
 {
     uint32_t rb[8];
-    int cj[8];
 #pragma unroll
-    for (int jl = 0; jl < 8; jl++) { rb[jl] = (rword >> (28 - 4 * jl)) & 15u; cj[jl] = crel0 + jl; }
+    for (int jl = 0; jl < 8; jl++) rb[jl] = (rword >> (28 - 4 * jl)) & 15u;
     unsigned long long km[15], rm[8];
     if (MASKED) {
 #pragma unroll
-        for (int kk = 0; kk < 15; kk++) km[kk] = __builtin_amdgcn_ballot_w64((kk - 7) <= tu && (7 - kk) <= tl);
+        for (int kk = 0; kk < 15; kk++)     // tu, tl >= -7 always, so kk = 0 never fails the first test and kk = 14 never the second
+            km[kk] = (kk == 0 ? ~0ull : __builtin_amdgcn_ballot_w64((kk - 7) <= tu)) &
+                     (kk == 14 ? ~0ull : __builtin_amdgcn_ballot_w64((7 - kk) <= tl));
 #pragma unroll
         for (int il = 0; il < 8; il++) rm[il] = __builtin_amdgcn_ballot_w64(il < nrows);
     }
@@ -114,7 +118,7 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
 #pragma unroll
                 for (int jl = 0; jl < 8; jl++) {
                     const int d = (jl == 0) ? ((il == 0) ? corner : rh[il - 1]) : h[jl - 1];
-                    if (qb == N_VALUE || rb[jl] == N_VALUE) t[jl] = d - 1;
+                    if (qb == N_VALUE || rb[jl] == N_VALUE) t[jl] = d - (1 << K);
                 }
             }
             // every diagonal term is taken from the PREVIOUS row's H: pin them before H is overwritten
@@ -129,7 +133,7 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
                     f[jl] = imax(tg, f[jl] - ge);
                     ev = imax(tg, ev - ge);
                     h[jl] = hn;
-                    A[il + jl] = imax(A[il + jl], (int)(((uint32_t)hn << K) + (uint32_t)cj[jl]));
+                    A[il + jl] = imax(A[il + jl], hn + crel0 + jl);      // one v_add3: low K bits of hn are zero
                 }
             }
             oh[il] = h[7]; e[il] = ev;
@@ -158,16 +162,18 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
     constexpr int GS = G * S;
     constexpr int K = KeyBits<GS>::value;
     constexpr int KMASK = (1 << K) - 1;
+    constexpr int NEGK = NEG_INF2 * (1 << K);
 
     const int lane = threadIdx.x & 63;
     const int k = lane & (G - 1);                 // lane inside the group
     const int gbase = lane & ~(G - 1);            // first lane of the group
     const int left_lane = gbase | ((k + G - 1) & (G - 1));
 
-    const int gapoe = P.gap_open + P.gap_extend, ge = P.gap_extend;
+    // everything that is a SCORE lives in the shifted domain (x << K); lengths, positions and z stay plain
+    const int gapoe = (P.gap_open + P.gap_extend) << K, ge = P.gap_extend << K;
     const int sw = P.slice_width, z = P.z_threshold, w = P.band_width;
     const int W = (w + 7) >> 3;
-    int va = P.match, vnb = -P.mismatch;          // kept in VGPRs: both arms of the score select
+    int va = P.match << K, vnb = -(P.mismatch << K);   // kept in VGPRs: both arms of the score select
     asm volatile("" : "+v"(va), "+v"(vnb));
 
     // ---- per-pair state (uniform inside a group) ----
@@ -219,7 +225,7 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
 #pragma unroll
                     for (int s = 0; s < S; s++) {
                         rcur[s] = k * S + s;
-                        init_col(rcur[s], R, w, gapoe, ge, h[s], f[s], corner[s]);
+                        init_col(rcur[s], R, w, gapoe, ge, NEGK, h[s], f[s], corner[s]);
                         rword[s] = (rcur[s] < prl) ? pt[rcur[s]] : 0xEEEEEEEEu;
                     }
 #pragma unroll
@@ -259,7 +265,7 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
             if (active) {
                 if (y == 0 && r == prl - 1) {   // pass start: padded ref columns fall back to -inf (agatha_kernel.h:207-215)
 #pragma unroll
-                    for (int m = 0; m < 8; m++) if (8 * r + m >= R) { h[s][m] = NEG_INF2; f[s][m] = NEG_INF2; }
+                    for (int m = 0; m < 8; m++) if (8 * r + m >= R) { h[s][m] = NEGK; f[s][m] = NEGK; }
                 }
                 const bool left_ok = (xr[s] == r - 1);
                 int rh[8];
@@ -269,16 +275,16 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
                     for (int il = 0; il < 8; il++) {
                         const int row = 8 * q + il;
                         const int kk = -(gapoe + ge * row);
-                        const int ih = (row <= w) ? kk : NEG_INF2;            // H(row, -1)   (agatha_kernel.h:126-131)
-                        const int ie = (row <= w) ? kk - gapoe : NEG_INF2;    // E(row, 0)
+                        const int ih = (row <= w) ? kk : NEGK;                // H(row, -1)   (agatha_kernel.h:126-131)
+                        const int ie = (row <= w) ? kk - gapoe : NEGK;        // E(row, 0)
                         rh[il] = left_ok ? xh[s][il] : ih;
                         xe[s + 1][il] = left_ok ? xe[s][il] : ie;             // E travels in place through the block
                     }
                 } else {
 #pragma unroll
                     for (int il = 0; il < 8; il++) {
-                        rh[il] = left_ok ? xh[s][il] : NEG_INF2;
-                        xe[s + 1][il] = left_ok ? xe[s][il] : NEG_INF2;
+                        rh[il] = left_ok ? xh[s][il] : NEGK;
+                        xe[s + 1][il] = left_ok ? xe[s][il] : NEGK;
                     }
                 }
                 const int tu = boundary ? w + 8 * q - 8 * r : 1000;     // cell skipped when jl - il > tu (:33)
@@ -309,7 +315,7 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
                 else if (c >= best_t && (d - c) >= best_q) {
                     const int tlen = c - best_t, qlen = (d - c) - best_q;
                     const int l = tlen > qlen ? tlen - qlen : qlen - tlen;
-                    if (z >= 0 && best - H > z + l * ge) stopped = true;
+                    if (z >= 0 && best - H > z + l * P.gap_extend) stopped = true;
                 }
             }
         }
@@ -333,7 +339,7 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
                 if (adv[s]) {
                     const int rn = rcur[s] + GS;
                     rcur[s] = rn;
-                    init_col(rn, R, w, gapoe, ge, h[s], f[s], corner[s]);
+                    init_col(rn, R, w, gapoe, ge, NEGK, h[s], f[s], corner[s]);
                     rword[s] = (rn < prl) ? pt[rn] : 0xEEEEEEEEu;
                 }
             }
