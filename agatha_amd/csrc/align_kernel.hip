@@ -94,18 +94,16 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
     uint32_t rb[8];
 #pragma unroll
     for (int jl = 0; jl < 8; jl++) rb[jl] = (rword >> (28 - 4 * jl)) & 15u;
-    unsigned long long km[15], rm[8];
+    unsigned long long km[15];
     if (MASKED) {
 #pragma unroll
         for (int kk = 0; kk < 15; kk++)     // tu, tl >= -7 always, so kk = 0 never fails the first test and kk = 14 never the second
             km[kk] = (kk == 0 ? ~0ull : __builtin_amdgcn_ballot_w64((kk - 7) <= tu)) &
                      (kk == 14 ? ~0ull : __builtin_amdgcn_ballot_w64((7 - kk) <= tl));
-#pragma unroll
-        for (int il = 0; il < 8; il++) rm[il] = __builtin_amdgcn_ballot_w64(il < nrows);
     }
 #pragma unroll
     for (int il = 0; il < 8; il++) {
-        if (!MASKED || __builtin_amdgcn_inverse_ballot_w64(rm[il])) {
+        if (!MASKED || il < nrows) {            // rows past the end of the query exist only in the last row block
             const uint32_t qb = (qword >> (28 - 4 * il)) & 15u;
             int t[8];
 #pragma unroll
@@ -152,13 +150,10 @@ __device__ __forceinline__ bool word_has_n(uint32_t v)
 
 template <int G, int S>
 __global__ void __launch_bounds__(256, (S <= 3 ? 2 : 1))
-align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__ packed_t,
-             const uint32_t* __restrict__ qlens, const uint32_t* __restrict__ tlens,
-             const uint32_t* __restrict__ qoffs, const uint32_t* __restrict__ toffs,
-             const uint32_t* __restrict__ order, int n, unsigned int* __restrict__ queue,
-             int32_t* __restrict__ out_score, int32_t* __restrict__ out_qend, int32_t* __restrict__ out_tend,
-             AlignParams P)
+align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
 {
+    // Batch pointers are read from the launch record only where a pair starts or ends: keeping a dozen 64-bit
+    // pointers live through the DP loop would push the band masks (30 SGPRs) into spills.
     constexpr int GS = G * S;
     constexpr int K = KeyBits<GS>::value;
     constexpr int KMASK = (1 << K) - 1;
@@ -174,12 +169,13 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
     const int sw = P.slice_width, z = P.z_threshold, w = P.band_width;
     const int W = (w + 7) >> 3;
     int va = P.match << K, vnb = -(P.mismatch << K);   // kept in VGPRs: both arms of the score select
-    asm volatile("" : "+v"(va), "+v"(vnb));
+    int vgapoe = gapoe, vge = ge;                      // VGPR copies: v_sub with two VGPR operands issues in half the
+    asm volatile("" : "+v"(va), "+v"(vnb), "+v"(vgapoe), "+v"(vge));   // cycles of the SGPR-operand form (tools/microbench)
 
     // ---- per-pair state (uniform inside a group) ----
     int Q = 0, R = 0, pql = 0, prl = 0, total = 0, lim = 0, pair = 0;
-    const uint32_t* pq = packed_q;
-    const uint32_t* pt = packed_t;
+    const uint32_t* pq = nullptr;
+    const uint32_t* pt = nullptr;
     int i = 0, y = 0, ss = 0, se = 0, cb_prev = 0;
     bool alive = false, exhausted = false, final_step = false;
     int best = 0, best_t = 0, best_q = 0;
@@ -207,15 +203,15 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
         const bool need = !alive && !exhausted;
         if (__any(need)) {
             int idx = 0;
-            if (need && k == 0) idx = (int)atomicAdd(queue, 1u);
+            if (need && k == 0) idx = (int)atomicAdd(La->queue, 1u);
             idx = lane_read(idx, gbase);
             if (need) {
-                if (idx >= n) exhausted = true;
+                if (idx >= La->n) exhausted = true;
                 else {
-                    pair = (int)order[idx];
-                    Q = (int)qlens[pair]; R = (int)tlens[pair];
-                    pq = packed_q + (qoffs[pair] >> 3);
-                    pt = packed_t + (toffs[pair] >> 3);
+                    pair = (int)La->order[idx];
+                    Q = (int)La->qlens[pair]; R = (int)La->tlens[pair];
+                    pq = La->packed_q + (La->qoffs[pair] >> 3);
+                    pt = La->packed_t + (La->toffs[pair] >> 3);
                     pql = (Q + 7) >> 3; prl = (R + 7) >> 3;
                     total = prl + pql - 1; lim = Q + R - 1;
                     best = 0; best_t = 0; best_q = 0;
@@ -234,7 +230,7 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
                     for (int x = 0; x < 15; x++) A[x] = INT_MIN;
                     alive = true;
                     if (Q <= 0 || R <= 0) {           // nothing to align
-                        if (k == 0) { out_score[pair] = 0; out_qend[pair] = 0; out_tend[pair] = 0; }
+                        if (k == 0) { La->score[pair] = 0; La->qend[pair] = 0; La->tend[pair] = 0; }
                         alive = false;
                     }
                 }
@@ -293,7 +289,7 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
                 // Edge blocks (band test) exist on every anti-diagonal, so a mask-free variant would rarely run for
                 // a whole wave; Ns are rare (padding of the last column block, occasional N in a read).
                 const bool any_n = __any(word_has_n(qword) || word_has_n(rw));
-                block8x8<true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, va, vnb, gapoe, ge, crel0, nrows, tu, tl, any_n);
+                block8x8<true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, va, vnb, vgapoe, vge, crel0, nrows, tu, tl, any_n);
             }
         }
         // X[S] of the left neighbour lane becomes X[0]
@@ -357,7 +353,7 @@ align_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__
             }
         }
         if (finished) {
-            if (k == 0) { out_score[pair] = best; out_qend[pair] = best_q; out_tend[pair] = best_t; }   // :359-363
+            if (k == 0) { La->score[pair] = best; La->qend[pair] = best_q; La->tend[pair] = best_t; }   // :359-363
             alive = false;
         }
     }
@@ -448,9 +444,7 @@ static hipError_t launch_align_t(const AlignLaunch& L, hipStream_t st)
     const int max_blocks = L.num_cus * 2;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((align_kernel<G, S>), dim3(blocks), dim3(256), 0, st,
-                       L.packed_q, L.packed_t, L.qlens, L.tlens, L.qoffs, L.toffs, L.order, L.n, L.queue,
-                       L.score, L.qend, L.tend, L.p);
+    hipLaunchKernelGGL((align_kernel<G, S>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
     return hipGetLastError();
 }
 
@@ -463,6 +457,14 @@ static const Cfg kCfgs[] = {
 };
 
 int max_window_blocks() { return 64 * 6; }
+
+__global__ void record_kernel(AlignLaunch L, AlignLaunch* rec) { *rec = L; *L.queue = 0u; }
+
+hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st)
+{
+    hipLaunchKernelGGL(record_kernel, dim3(1), dim3(1), 0, st, L, rec);
+    return hipGetLastError();
+}
 
 hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint32_t* hist, uint32_t nbuckets,
                        uint32_t* order, hipStream_t st)

@@ -66,7 +66,8 @@ int agatha_amd_max_band(void) { return (agatha::max_window_blocks() - 1) * 8; }
 
 size_t agatha_amd_workspace_bytes(uint32_t max_n_alns)
 {
-    return round_up(sizeof(uint32_t) * (size_t)max_n_alns) + round_up(sizeof(uint32_t) * kBuckets) + kAlign;
+    return round_up(sizeof(uint32_t) * (size_t)max_n_alns) + round_up(sizeof(uint32_t) * kBuckets) + kAlign +
+           round_up(sizeof(agatha::AlignLaunch));
 }
 
 int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, uint32_t* d_packed)
@@ -102,10 +103,10 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     char* ws = (char*)d_workspace;
     uint32_t* order = (uint32_t*)ws;             ws += round_up(sizeof(uint32_t) * (size_t)n_alns);
     uint32_t* hist = (uint32_t*)ws;              ws += round_up(sizeof(uint32_t) * kBuckets);
-    unsigned int* queue = (unsigned int*)ws;
+    unsigned int* queue = (unsigned int*)ws;     ws += kAlign;
+    agatha::AlignLaunch* rec = (agatha::AlignLaunch*)ws;
 
     HIPCHK(agatha::launch_sort(d_query_lens, d_target_lens, (int)n_alns, hist, kBuckets, order, st));
-    HIPCHK(hipMemsetAsync(queue, 0, sizeof(unsigned int), st));
 
     agatha::AlignLaunch L;
     L.packed_q = d_packed_query; L.packed_t = d_packed_target;
@@ -114,6 +115,8 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.score = d_aln_score; L.qend = d_query_batch_end; L.tend = d_target_batch_end;
     L.p = {sc->match, sc->mismatch, sc->gap_open, sc->gap_extend, sc->slice_width, sc->z_threshold, sc->band_width};
     L.num_cus = num_cus();
+    L.self_dev = rec;
+    HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record + queue head reset, stream-ordered
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));
     HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st));
     if (g_ev1) HIPCHK(hipEventRecord(g_ev1, st));

@@ -32,9 +32,22 @@ def algorithmic_bytes(qlen, tlen):
     return int((4 * q + 4 * t + 28).sum())
 
 
+def effective_cpus():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but cpu.max = 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(O, qb, tb, qo, to, ql, tl, params, w, budget_s=12.0):
     """The oracle (a scalar C port of the reference recurrence) on a bounded sample, OpenMP over pairs."""
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     n = len(ql)
     k0 = min(n, 2 * cores)
     t0 = time.time()

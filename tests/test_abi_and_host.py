@@ -1,0 +1,79 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/agatha_amd.h declares; the C++ host layer
+(GASAL API + CLI) builds, links and honours the reference's argument contract.  No compute calls (no GPU here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "agatha_amd", "libagatha_amd.so")
+MANUAL = os.path.join(ROOT, "agatha_amd", "manual")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not (os.path.exists(LIB) and os.path.exists(MANUAL)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+def test_every_declared_symbol_is_exported():
+    import agatha_amd
+    lib = agatha_amd.load_library()
+    hdr = open(os.path.join(ROOT, "include", "agatha_amd.h")).read()
+    names = set(re.findall(r"\b(agatha_amd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    from agatha_amd import engine
+    assert set(engine.EXPORTS) == names
+
+
+def test_abi_struct_matches_reference_layout():
+    import ctypes as C
+    import agatha_amd
+    # seven int32 in the order of the reference's gasal_subst_scores (gasal.h:165-173)
+    assert [f[0] for f in agatha_amd.Scores._fields_] == ["match", "mismatch", "gap_open", "gap_extend", "slice_width",
+                                                           "z_threshold", "band_width"]
+    assert C.sizeof(agatha_amd.Scores) == 28
+
+
+def test_library_reports_limits_without_a_gpu():
+    import agatha_amd
+    lib = agatha_amd.load_library()
+    assert lib.agatha_amd_max_band() >= 1500          # BASELINE config 3 needs band 1500
+    assert lib.agatha_amd_workspace_bytes(8192) < (1 << 20)
+    assert lib.agatha_amd_strerror(-2).decode().startswith("band")
+
+
+def test_engine_fails_loudly_without_gpu():
+    import agatha_amd
+    if agatha_amd.load_library().agatha_amd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(agatha_amd.AgathaError):
+        agatha_amd.Engine(0)
+
+
+def test_gasal_host_library_exports_the_reference_api():
+    out = subprocess.check_output(["nm", "-DC", os.path.join(ROOT, "agatha_amd", "libgasal_amd.so")], text=True)
+    for sym in ["gasal_copy_subst_scores", "gasal_init_gpu_storage_v", "gasal_init_streams", "gasal_host_batch_fill",
+                "gasal_host_alns_resize", "gasal_op_fill", "gasal_aln_async", "gasal_is_aln_async_done",
+                "gasal_destroy_streams", "gasal_destroy_gpu_storage_v", "gasal_set_device", "gasal_host_batch_reset",
+                "gasal_res_new_host", "Parameters::parse"]:
+        assert sym in out, sym
+
+
+def test_cli_argument_contract(tmp_path):
+    # --help anywhere prints usage and exits 0 (args_parser.cpp:101-110)
+    r = subprocess.run([MANUAL, "-h"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage" in r.stderr
+    # argc < 4 is refused (args_parser.cpp:112): a bare `manual q.fa t.fa` fails
+    r = subprocess.run([MANUAL, "a.fa", "b.fa"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Not enough" in r.stderr
+    # missing files -> WRONG_FILES, exit 1
+    r = subprocess.run([MANUAL, "-m", "2", str(tmp_path / "nope1.fa"), str(tmp_path / "nope2.fa")], capture_output=True, text=True)
+    assert r.returncode == 1 and "File error" in r.stderr
+    # multi-letter option packs are refused
+    r = subprocess.run([MANUAL, "-sp", "1", str(tmp_path / "a"), str(tmp_path / "b")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Wrong argument" in r.stderr

@@ -1,0 +1,72 @@
+"""GPU: the GASAL-compatible C++ host layer + `manual` CLI end to end (FASTA -> batches -> score lines)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MANUAL = os.path.join(ROOT, "agatha_amd", "manual")
+
+
+def write_fasta(path, seqs, width=70, header=">>> "):
+    with open(path, "w") as f:
+        for k, s in enumerate(seqs):
+            s = s.decode() if isinstance(s, bytes) else s
+            f.write(f"{header}{k + 1}\n")
+            for i in range(0, len(s), width):
+                f.write(s[i:i + width] + "\n")
+
+
+def parse(out):
+    res = []
+    for line in out.strip().splitlines():
+        a, b, c = line.split("\t")
+        assert b.startswith("query_batch_end=") and c.startswith("target_batch_end=")
+        res.append((int(a), int(b.split("=")[1]), int(c.split("=")[1])))
+    return np.array(res, np.int64)
+
+
+@pytest.mark.parametrize("threads,align_num", [(1, 8192), (1, 100), (3, 64)])
+def test_cli_matches_oracle(tmp_path, threads, align_num):
+    qs, ts = synth.cfg_c4(n=300, seed=99, lo=100, hi=4000)
+    f1, f2, raw = tmp_path / "ref.fasta", tmp_path / "query.fasta", tmp_path / "raw.log"
+    write_fasta(f1, qs, width=61)
+    write_fasta(f2, ts, width=80)          # different line counts per record: the reader must not care
+    cmd = [MANUAL, "-p", "-m", "1", "-x", "4", "-q", "6", "-r", "2", "-s", "3", "-z", "400", "-w", "751",
+           "-a", str(align_num), "-n", str(threads), str(f1), str(f2), str(raw)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = parse(r.stdout)
+    exp = np.stack(O.align_pairs(qs, ts, O.make_params(m=1, x=4, q=6, r=2, s=3, z=400, w=751), wide=True,
+                                 threads=4), axis=1)
+    assert got.shape == exp.shape
+    # Lines are in input order inside a batch; batches are printed in the order their streams are seen to finish
+    # (two streams per host thread, exactly as the reference's test_prog.cpp:355-374), so match batch by batch.
+    per_thread = -(-300 // threads)
+    batches = []
+    for t in range(threads):
+        lo, hi = t * per_thread, min(300, (t + 1) * per_thread)
+        batches += [exp[k:min(k + align_num, hi)] for k in range(lo, hi, align_num)]
+    pos, unused = 0, list(range(len(batches)))
+    while pos < len(got):
+        hit = [k for k in unused if (got[pos:pos + len(batches[k])] == batches[k]).all()]
+        assert hit, f"printed block at line {pos} matches no batch"
+        pos += len(batches[hit[0]])
+        unused.remove(hit[0])
+    assert not unused
+    lines = open(raw).read().split()
+    n_batches = sum(-(-c // align_num) for c in ([300] if threads == 1 else [100, 100, 100]))
+    assert len(lines) == n_batches and all(float(x) > 0 for x in lines)
+
+
+def test_cli_silent_without_p(tmp_path):
+    qs, ts = synth.make_pairs(3, 10, lambda r: 200)
+    f1, f2 = tmp_path / "a.fa", tmp_path / "b.fa"
+    write_fasta(f1, qs, header=">")
+    write_fasta(f2, ts, header=">")
+    r = subprocess.run([MANUAL, "-w", "100", str(f1), str(f2)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout == ""
