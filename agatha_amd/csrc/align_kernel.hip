@@ -89,17 +89,29 @@ template <bool MASKED, int K>
 __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, const int (&rh)[8], int (&e)[8],
                                          int (&oh)[8], int (&A)[15], uint32_t qword, uint32_t rword,
                                          int va, int vnb, int gapoe, int ge, int crel0, int nrows, int tu, int tl,
-                                         bool any_n)
+                                         int t0, bool any_n)
 {
     uint32_t rb[8];
 #pragma unroll
     for (int jl = 0; jl < 8; jl++) rb[jl] = (rword >> (28 - 4 * jl)) & 15u;
     unsigned long long km[15];
     if (MASKED) {
+        // Away from the matrix corners an edge block has tu == t0 (upper edge) or tl == t0 (lower edge), t0 = w - 8W,
+        // and every other block has no skipped cell: then the 15 lane masks are two ballots combined with
+        // wave-uniform predicates in SALU.  Anything else (clamped corners, bands narrower than a block) takes the
+        // general per-lane compares.
+        const bool up = (tu == t0) && (tl >= 7), lo = (tl == t0) && (tu >= 7), none = (tu >= 7) && (tl >= 7);
+        if (__all(up || lo || none)) {
+            const unsigned long long mu = __builtin_amdgcn_ballot_w64(up), ml = __builtin_amdgcn_ballot_w64(lo);
 #pragma unroll
-        for (int kk = 0; kk < 15; kk++)     // tu, tl >= -7 always, so kk = 0 never fails the first test and kk = 14 never the second
-            km[kk] = (kk == 0 ? ~0ull : __builtin_amdgcn_ballot_w64((kk - 7) <= tu)) &
-                     (kk == 14 ? ~0ull : __builtin_amdgcn_ballot_w64((7 - kk) <= tl));
+            for (int kk = 0; kk < 15; kk++)
+                km[kk] = ~(((kk - 7) > t0 ? mu : 0ull) | ((7 - kk) > t0 ? ml : 0ull));
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 15; kk++)     // tu, tl >= -7 always, so kk = 0 never fails the first test and kk = 14 never the second
+                km[kk] = (kk == 0 ? ~0ull : __builtin_amdgcn_ballot_w64((kk - 7) <= tu)) &
+                         (kk == 14 ? ~0ull : __builtin_amdgcn_ballot_w64((7 - kk) <= tl));
+        }
     }
 #pragma unroll
     for (int il = 0; il < 8; il++) {
@@ -289,7 +301,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                 // Edge blocks (band test) exist on every anti-diagonal, so a mask-free variant would rarely run for
                 // a whole wave; Ns are rare (padding of the last column block, occasional N in a read).
                 const bool any_n = __any(word_has_n(qword) || word_has_n(rw));
-                block8x8<true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, va, vnb, vgapoe, vge, crel0, nrows, tu, tl, any_n);
+                block8x8<true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, va, vnb, vgapoe, vge, crel0, nrows, tu, tl, w - 8 * W, any_n);
             }
         }
         // X[S] of the left neighbour lane becomes X[0]
@@ -299,19 +311,43 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
 
         // ------------------------------------------------------------------ anti-diagonals 8i..8i+7 are complete
         bool stopped = false;
+        int vred[8];
 #pragma unroll
-        for (int x = 0; x < 8; x++) {
-            const int v = group_max<G>(A[x], lane);
-            const int d = 8 * i + x;
-            const bool chk = alive && !stopped && (final_step || d < lim);           // agatha_kernel.h:293-294 / 337
-            int H = v >> K, c = (v & KMASK) + cb;
-            if (v == INT_MIN) { H = -32768; c = 0; }                                  // empty anti-diagonal
-            if (chk) {                                                               // agatha_kernel.h:297-309
-                if (H > best) { best = H; best_t = c; best_q = d - c; }
-                else if (c >= best_t && (d - c) >= best_q) {
-                    const int tlen = c - best_t, qlen = (d - c) - best_q;
-                    const int l = tlen > qlen ? tlen - qlen : qlen - tlen;
-                    if (z >= 0 && best - H > z + l * P.gap_extend) stopped = true;
+        for (int x = 0; x < 8; x++) vred[x] = group_max<G>(A[x], lane);
+        // Fast path (wave-uniform): every anti-diagonal of this step is non-empty, inside the pair, and within z of the
+        // running maximum, so z-drop cannot fire (agatha_kernel.h:304 needs best - H > z + l*ge >= z) and only the
+        // running maximum and its position have to be advanced.
+        bool calm = !final_step && (8 * i + 7 < lim);
+        {
+            int lo8 = vred[0];
+#pragma unroll
+            for (int x = 1; x < 8; x++) lo8 = imin(lo8, vred[x]);
+            int hi8 = vred[0];
+#pragma unroll
+            for (int x = 1; x < 8; x++) hi8 = imax(hi8, vred[x]);
+            calm = calm && lo8 != INT_MIN && (z < 0 || imax(best, hi8 >> K) - (lo8 >> K) <= z);
+        }
+        if (__all(calm || !alive)) {
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                const int H = vred[x] >> K;
+                if (alive && H > best) { best = H; best_t = (vred[x] & KMASK) + cb; best_q = 8 * i + x - best_t; }
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                const int v = vred[x];
+                const int d = 8 * i + x;
+                const bool chk = alive && !stopped && (final_step || d < lim);       // agatha_kernel.h:293-294 / 337
+                int H = v >> K, c = (v & KMASK) + cb;
+                if (v == INT_MIN) { H = -32768; c = 0; }                              // empty anti-diagonal
+                if (chk) {                                                           // agatha_kernel.h:297-309
+                    if (H > best) { best = H; best_t = c; best_q = d - c; }
+                    else if (c >= best_t && (d - c) >= best_q) {
+                        const int tlen = c - best_t, qlen = (d - c) - best_q;
+                        const int l = tlen > qlen ? tlen - qlen : qlen - tlen;
+                        if (z >= 0 && best - H > z + l * P.gap_extend) stopped = true;
+                    }
                 }
             }
         }
