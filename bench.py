@@ -21,7 +21,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md)
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
+# int32 VALU roof: v_max/v_max3/v_add3/v_cndmask/v_cmp sustain ~15 lanes/clk/SIMD on this chip (4 cycles per wave64
+# instruction; tools/microbench/valu_rate.hip, profiles/r01_v1/valu_issue_rate_microbench.txt) -> 256 CU x 4 SIMD x 16 x 2.4 GHz
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 OPS_PER_CELL = 11                     # algorithmic int32 ops of one DP cell incl. the anti-diagonal maximum
 
 
@@ -151,6 +153,14 @@ def main():
     else:
         total_cells, total_pairs = float(cells), float(b.n)
 
+    # HBM bytes per launch measured with rocprofv3 PMC counters in a separate profiled run of this same command
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        if pm.get("pairs") == a.pairs:
+            traffic = float(pm["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
     kms = [eng.elapsed_ms(e0, e1) for e0, e1 in kev] if a.steps else [float("nan")]
     kernel_ms = float(np.mean(kms))
     G, S = eng.last_config()
@@ -177,7 +187,9 @@ def main():
             "kernel_ms": kernel_ms,
             "kernel_gcups_rank0": cells / kernel_ms / 1e6,
             "roofline": {"bound": "hbm", "achieved": abytes / kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": abytes / kernel_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": abytes / kernel_ms / 1e6 / HBM_PEAK_GBS,
+                         "traffic": (traffic / kernel_ms / 1e6) if traffic else None,
+                         "algorithmic_bytes_per_launch": abytes, "traffic_bytes_per_launch": traffic,
                          "kernel": f"agatha::align_kernel<{G},{S}>",
                          "note": "integer max/add DP at ~1400 cells per algorithmic byte: the HBM roof is not binding, "
                                  "see roofline_valu (DESIGN.md, SURVEY.md 8(d))"},
