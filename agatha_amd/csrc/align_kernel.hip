@@ -469,6 +469,61 @@ pack_kernel(const uint4* __restrict__ in16, uint2* __restrict__ out8, uint32_t n
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Per-sequence reverse / complement (replaces gasal_reversecomplement_kernel, pack_rc_seqs.h:56-212, which the
+// reference runs in place on the packed words with one thread per pair).  Here the packed words of a sequence
+// whose op code is non-zero are simply re-derived from the unpacked ASCII that is still in HBM: one wave per
+// sequence, coalesced word stores, no in-place hazards.  op bit 0 = reverse, bit 1 = complement (A<->T, C<->G;
+// every other code is left alone, pack_rc_seqs.h:183-199).  Reversal uses the TRUE length: base p becomes old base
+// len-1-p, positions >= len of the last word stay N.  (As written, the reference counts padding Ns by comparing a
+// nibble with N_CODE = 0x4E and therefore always finds zero, so for len % 8 != 0 it rotates the padding to the
+// front; for len % 8 == 0 both agree.  See DESIGN.md.)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t comp_code(uint32_t c)
+{
+    return c == 1u ? 4u : c == 4u ? 1u : c == 3u ? 7u : c == 7u ? 3u : c;
+}
+
+__global__ void __launch_bounds__(256)
+seq_ops_kernel(const uint8_t* __restrict__ unpacked, uint32_t* __restrict__ packed, const uint32_t* __restrict__ lens,
+               const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ ops, uint32_t n)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t s = wave; s < n; s += nwaves) {
+        const uint32_t op = ops[s] & 3u;
+        if (op == 0u) continue;
+        const uint32_t len = lens[s], off = offsets[s];
+        const uint32_t nw = (len + 7u) >> 3;
+        const uint8_t* src = unpacked + off;
+        uint32_t* dst = packed + (off >> 3);
+        for (uint32_t wi = lane; wi < nw; wi += 64u) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint32_t p = 8u * wi + k;
+                uint32_t c = N_VALUE;
+                if (p < len) {
+                    c = (uint32_t)src[(op & 1u) ? (len - 1u - p) : p] & 15u;
+                    if (op & 2u) c = comp_code(c);
+                }
+                v |= c << (28u - 4u * k);
+            }
+            dst[wi] = v;
+        }
+    }
+}
+
+hipError_t launch_seq_ops(const uint8_t* unpacked, uint32_t* packed, const uint32_t* lens, const uint32_t* offsets,
+                          const uint8_t* ops, uint32_t n, hipStream_t st)
+{
+    uint32_t blocks = (n + 3u) / 4u;
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks < 1u) blocks = 1u;
+    hipLaunchKernelGGL(seq_ops_kernel, dim3(blocks), dim3(256), 0, st, unpacked, packed, lens, offsets, ops, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host-side launchers (called from capi.cpp through kernels.h)
 // ---------------------------------------------------------------------------------------------------
 template <int G, int S>

@@ -77,6 +77,14 @@ int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, ui
     return 0;
 }
 
+int agatha_amd_seq_ops(void* stream, const uint8_t* d_unpacked, uint32_t* d_packed, const uint32_t* d_lens,
+                       const uint32_t* d_offsets, const uint8_t* d_ops, uint32_t n_seqs)
+{
+    if (!d_unpacked || !d_packed || !d_lens || !d_offsets || !d_ops || n_seqs == 0) return AGATHA_AMD_EINVAL;
+    HIPCHK(agatha::launch_seq_ops(d_unpacked, d_packed, d_lens, d_offsets, d_ops, n_seqs, (hipStream_t)stream));
+    return 0;
+}
+
 int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
                      const uint32_t* d_query_lens, const uint32_t* d_target_lens,
                      const uint32_t* d_query_offsets, const uint32_t* d_target_offsets,

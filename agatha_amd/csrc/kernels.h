@@ -25,6 +25,8 @@ int max_window_blocks();
 hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st);
 hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint32_t* hist, uint32_t nbuckets,
                        uint32_t* order, hipStream_t st);
+hipError_t launch_seq_ops(const uint8_t* unpacked, uint32_t* packed, const uint32_t* lens, const uint32_t* offsets,
+                          const uint8_t* ops, uint32_t n, hipStream_t st);
 hipError_t launch_pack(const uint8_t* unpacked, uint32_t nbytes, uint32_t* packed, hipStream_t st);
 
 }  // namespace agatha

@@ -67,6 +67,7 @@ def load_library():
     lib.agatha_amd_workspace_bytes.restype = C.c_size_t
     lib.agatha_amd_workspace_bytes.argtypes = [C.c_uint32]
     lib.agatha_amd_pack.argtypes = [vp, vp, C.c_uint32, u32p]
+    lib.agatha_amd_seq_ops.argtypes = [vp, vp, u32p, u32p, u32p, vp, C.c_uint32]
     lib.agatha_amd_align.argtypes = [vp, u32p, u32p, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.POINTER(Scores), i32p, i32p, i32p, vp, C.c_size_t]
     lib.agatha_amd_set_kernel_events.argtypes = [vp, vp]
@@ -94,7 +95,7 @@ def load_library():
 EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack",
-    "agatha_amd_align", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -170,6 +171,20 @@ class DeviceBatch:
         _chk(lib, lib.agatha_amd_pack(st, self.d_unp_q.ptr, self.qbytes, self.d_pk_q.ptr))
         _chk(lib, lib.agatha_amd_pack(st, self.d_unp_t.ptr, self.tbytes, self.d_pk_t.ptr))
 
+    def seq_ops(self, qops=None, tops=None, stream=None):
+        """Apply per-sequence reverse/complement op codes (0..3) to the packed batch; call after pack()."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        for ops, unp, pk, ln, of in ((qops, self.d_unp_q, self.d_pk_q, self.d_meta[2], self.d_meta[0]),
+                                     (tops, self.d_unp_t, self.d_pk_t, self.d_meta[3], self.d_meta[1])):
+            if ops is None:
+                continue
+            h = np.ascontiguousarray(ops, np.uint8)
+            d = _DevBuf(lib, max(self.n, 1))
+            self._tmp = getattr(self, "_tmp", []) + [d, h]
+            _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, d.ptr, h.ctypes.data, self.n))
+            _chk(lib, lib.agatha_amd_seq_ops(st, unp.ptr, pk.ptr, ln.ptr, of.ptr, d.ptr, self.n))
+
     def align(self, scores, stream=None, use_len_hint=True):
         lib = self.eng.lib
         st = stream if stream is not None else self.eng.stream
@@ -200,6 +215,9 @@ class DeviceBatch:
     def free(self):
         for b in [self.d_unp_q, self.d_unp_t, self.d_pk_q, self.d_pk_t, self.d_ws] + self.d_meta + self.d_res:
             b.free()
+        for b in getattr(self, "_tmp", []):
+            if isinstance(b, _DevBuf):
+                b.free()
 
 
 class Engine:
@@ -226,11 +244,14 @@ class Engine:
     def batch(self, qbuf, tbuf, qoff, toff, qlen, tlen):
         return DeviceBatch(self, qbuf, tbuf, qoff, toff, qlen, tlen)
 
-    def align_host_batch(self, qbuf, tbuf, qoff, toff, qlen, tlen, scores, use_len_hint=True):
+    def align_host_batch(self, qbuf, tbuf, qoff, toff, qlen, tlen, scores, use_len_hint=True, qops=None, tops=None):
         """ASCII host batch in the GASAL wire format -> (score, query_end, target_end) int32 arrays."""
         b = self.batch(qbuf, tbuf, qoff, toff, qlen, tlen)
         try:
-            b.upload(); b.pack(); b.align(scores, use_len_hint=use_len_hint); b.download()
+            b.upload(); b.pack()
+            if qops is not None or tops is not None:
+                b.seq_ops(qops, tops)
+            b.align(scores, use_len_hint=use_len_hint); b.download()
             self.synchronize()
             return b.res_host[0].copy(), b.res_host[1].copy(), b.res_host[2].copy()
         finally:

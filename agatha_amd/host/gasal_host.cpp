@@ -375,6 +375,19 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
     CHK(agatha_amd_memcpy_h2d_async(s->str, s->query_batch_offsets, s->host_query_batch_offsets, mb));
     CHK(agatha_amd_memcpy_h2d_async(s->str, s->target_batch_offsets, s->host_target_batch_offsets, mb));
 
+    if (params->isReverseComplement) {          // gasal_align.cu:199-213
+        if (params->isPacked) {
+            fprintf(stderr, "[GASAL ERROR:] reverse/complement ops need the unpacked batch on the device (isPacked is set)\n");
+            exit(EXIT_FAILURE);
+        }
+        CHK(agatha_amd_memcpy_h2d_async(s->str, s->query_op, s->host_query_op, actual_n_alns));
+        CHK(agatha_amd_memcpy_h2d_async(s->str, s->target_op, s->host_target_op, actual_n_alns));
+        CHK(agatha_amd_seq_ops(s->str, s->unpacked_query_batch, s->packed_query_batch, s->query_batch_lens,
+                               s->query_batch_offsets, s->query_op, actual_n_alns));
+        CHK(agatha_amd_seq_ops(s->str, s->unpacked_target_batch, s->packed_target_batch, s->target_batch_lens,
+                               s->target_batch_offsets, s->target_op, actual_n_alns));
+    }
+
     uint32_t max_q = 0, max_t = 0;      // length hints: let short batches use a narrower lane group
     for (uint32_t k = 0; k < actual_n_alns; k++) {
         max_q = std::max(max_q, s->host_query_batch_lens[k]);

@@ -61,6 +61,13 @@ size_t agatha_amd_workspace_bytes(uint32_t max_n_alns);
  * nbytes must be a multiple of 8; d_unpacked 16-byte aligned; d_packed holds nbytes/8 words. */
 int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, uint32_t* d_packed);
 
+/* Per-sequence reverse / complement of one side of a batch, AFTER agatha_amd_pack().  Replaces the
+ * gasal_reversecomplement_kernel launch (gasal_align.cu:199-213; kernel pack_rc_seqs.h:56-212).  d_ops[k] bit 0 = reverse,
+ * bit 1 = complement (operation_on_seq, gasal.h:66-71); sequences with op 0 are left untouched.  Needs the unpacked ASCII
+ * of the batch still resident (it re-derives the affected packed words from it). */
+int agatha_amd_seq_ops(void* stream, const uint8_t* d_unpacked, uint32_t* d_packed, const uint32_t* d_lens,
+                       const uint32_t* d_offsets, const uint8_t* d_ops, uint32_t n_seqs);
+
 /* Sort + align one batch.  Replaces agatha_kernel_launcher (gasal_align.cu:10-23): the agatha_sort kernel,
  * its D2H / host std::sort / H2D round trip, and agatha_kernel itself.
  * max_query_len / max_target_len: upper bounds of the lengths in this batch (0 = unknown); they only let

@@ -70,3 +70,27 @@ def test_cli_silent_without_p(tmp_path):
     write_fasta(f2, ts, header=">")
     r = subprocess.run([MANUAL, "-w", "100", str(f1), str(f2)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout == ""
+
+
+def test_cli_op_codes_with_c_flag(tmp_path):
+    """-c (extension): header characters > < / + select forward / reverse / complement / reverse-complement."""
+    qs, ts = synth.make_pairs(8, 40, lambda r: int(r.integers(20, 900)))
+    ops_q = [">", "<", "/", "+"] * 10
+    ops_t = ["+", ">", "<", "/"] * 10
+    f1, f2, raw = tmp_path / "a.fa", tmp_path / "b.fa", tmp_path / "raw.log"
+    for path, seqs, ops in ((f1, qs, ops_q), (f2, ts, ops_t)):
+        with open(path, "w") as f:
+            for k, (s, o) in enumerate(zip(seqs, ops)):
+                f.write(f"{o}{k}\n{s.decode()}\n")
+    r = subprocess.run([MANUAL, "-p", "-c", "-w", "100", "-z", "200", str(f1), str(f2), str(raw)], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+
+    def tr(s, o):
+        k = "></+".index(o)
+        s = s[::-1] if k & 1 else s
+        return s.translate(comp) if k & 2 else s
+    exp = np.stack(O.align_pairs([tr(s, o) for s, o in zip(qs, ops_q)], [tr(s, o) for s, o in zip(ts, ops_t)],
+                                 O.make_params(w=100, z=200), wide=True), axis=1)
+    assert (parse(r.stdout) == exp).all()

@@ -101,3 +101,33 @@ def test_rejects_bad_arguments(eng):
         eng.align_host_batch(qb, qb, qo, qo, ql, ql, _scores(dict(w=10 ** 6)), use_len_hint=False)
     with pytest.raises(agatha_amd.AgathaError):
         eng.align_host_batch(qb[:4], qb, qo, qo, ql, ql, _scores({}))                 # bytes not a multiple of 8
+
+
+def _transform(seq, op):
+    comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    s = seq[::-1] if op & 1 else seq
+    return s.translate(comp) if op & 2 else s
+
+
+def test_reverse_complement_ops(eng):
+    """Header-char op codes (0 forward, 1 reverse, 2 complement, 3 reverse-complement): aligning with ops must equal
+    aligning the transformed strings.  Lengths include non-multiples of 8 and sequences with Ns."""
+    rng = np.random.default_rng(21)
+    qs, ts = synth.make_pairs(17, 64, lambda r: int(r.integers(1, 700)), 0.03, 0.03, 0.03, n_rate=0.01)
+    qops = rng.integers(0, 4, len(qs)).astype(np.uint8)
+    tops = rng.integers(0, 4, len(ts)).astype(np.uint8)
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=100, w=64)
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    got = eng.align_host_batch(qb, tb, qo, to, ql, tl, _scores(p), qops=qops, tops=tops)
+    exp = O.align_pairs([_transform(q, o) for q, o in zip(qs, qops)], [_transform(t, o) for t, o in zip(ts, tops)],
+                        O.make_params(**p), wide=True)
+    for a, b in zip(got, exp):
+        assert (a == b).all()
+    # the packed words themselves
+    b_ = eng.batch(qb, tb, qo, to, ql, tl)
+    b_.upload(); b_.pack(); b_.seq_ops(qops, tops)
+    pq, pt = b_.packed_host()
+    b_.free()
+    eq, _, _ = O.make_batch([_transform(q, o) for q, o in zip(qs, qops)])
+    assert (pq == O.pack(eq)).all()
