@@ -186,8 +186,11 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
 
     // ---- per-pair state (uniform inside a group) ----
     int Q = 0, R = 0, pql = 0, prl = 0, total = 0, lim = 0, pair = 0;
-    const uint32_t* pq = nullptr;
-    const uint32_t* pt = nullptr;
+    // sequence words are read through explicit global (address space 1) pointers: a pointer loaded from the launch
+    // record is otherwise treated as generic and costs flat_load + a wait on both memory counters
+    typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
+    gptr_t pq = nullptr;
+    gptr_t pt = nullptr;
     int i = 0, y = 0, ss = 0, se = 0, cb_prev = 0;
     bool alive = false, exhausted = false, final_step = false;
     int best = 0, best_t = 0, best_q = 0;
@@ -222,8 +225,8 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                 else {
                     pair = (int)La->order[idx];
                     Q = (int)La->qlens[pair]; R = (int)La->tlens[pair];
-                    pq = La->packed_q + (La->qoffs[pair] >> 3);
-                    pt = La->packed_t + (La->toffs[pair] >> 3);
+                    pq = (gptr_t)(La->packed_q + (La->qoffs[pair] >> 3));
+                    pt = (gptr_t)(La->packed_t + (La->toffs[pair] >> 3));
                     pql = (Q + 7) >> 3; prl = (R + 7) >> 3;
                     total = prl + pql - 1; lim = Q + R - 1;
                     best = 0; best_t = 0; best_q = 0;
@@ -548,6 +551,14 @@ static const Cfg kCfgs[] = {
 };
 
 int max_window_blocks() { return 64 * 6; }
+
+// bits of the packed-maximum key that hold the relative column for the (G, S) chosen for `window_blocks`
+int key_bits_for_window(int window_blocks)
+{
+    for (const Cfg& c : kCfgs)
+        if (c.G * c.S >= window_blocks) { int k = 7; while ((1 << k) < 8 * (c.G * c.S + 2)) k++; return k; }
+    return -1;
+}
 
 __global__ void record_kernel(AlignLaunch L, AlignLaunch* rec) { *rec = L; *L.queue = 0u; }
 

@@ -48,6 +48,7 @@ const char* agatha_amd_strerror(int code)
         case AGATHA_AMD_EBAND: return "band wider than the largest compiled window";
         case AGATHA_AMD_EWORKSPACE: return "workspace too small";
         case AGATHA_AMD_EHIP: return "HIP runtime error";
+        case AGATHA_AMD_ERANGE: return "scores can exceed the int32 range of the kernel for these lengths/band (pass length hints, lower -m or -w)";
         default: return "unknown error";
     }
 }
@@ -106,6 +107,14 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     if (max_target_len) window = std::min(window, ((long)max_target_len + 7) / 8);
     window = std::max(window, 1L);
     if (window > agatha::max_window_blocks()) return AGATHA_AMD_EBAND;
+    // scores are carried as H << K in int32: the largest possible score must stay below 2^(30-K)
+    {
+        const int K = agatha::key_bits_for_window((int)window);
+        const long lmax = (max_query_len && max_target_len) ? std::min<long>(max_query_len, max_target_len)
+                          : (long)std::max(max_query_len, max_target_len);
+        const long top = std::max<long>(lmax, 1) * std::max(sc->match, 1) + 16384 + 2L * (sc->band_width + 8) * sc->gap_extend;
+        if (K < 0 || top >= (1L << (30 - K))) return AGATHA_AMD_ERANGE;
+    }
 
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)d_workspace;

@@ -21,6 +21,7 @@ struct AlignLaunch {
 // window_blocks = blocks that can be live on one block-anti-diagonal; picks the smallest (G, S) covering it
 hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st);
 int max_window_blocks();
+int key_bits_for_window(int window_blocks);
 // writes L into *rec on the device (by-value kernel argument: no host-memory lifetime to care about) and zeroes *L.queue
 hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st);
 hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint32_t* hist, uint32_t nbuckets,

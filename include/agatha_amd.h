@@ -39,7 +39,8 @@ enum {
     AGATHA_AMD_EINVAL = -1,      /* bad argument (NULL pointer, size not a multiple of 8, n == 0 ...) */
     AGATHA_AMD_EBAND = -2,       /* band wider than the largest compiled window (agatha_amd_max_band()) */
     AGATHA_AMD_EWORKSPACE = -3,  /* workspace too small, see agatha_amd_workspace_bytes() */
-    AGATHA_AMD_EHIP = -4         /* HIP runtime error, text in agatha_amd_last_error() */
+    AGATHA_AMD_EHIP = -4,        /* HIP runtime error, text in agatha_amd_last_error() */
+    AGATHA_AMD_ERANGE = -5       /* match * min(max lengths) does not fit the kernel's 2^(30-K) score range (K = 8..13 by band) */
 };
 
 const char* agatha_amd_strerror(int code);
