@@ -247,6 +247,11 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                     if (Q <= 0 || R <= 0) {           // nothing to align
                         if (k == 0) { La->score[pair] = 0; La->qend[pair] = 0; La->tend[pair] = 0; }
                         alive = false;
+                    } else if (imin(W + 1, imin(pql, prl)) > GS) {
+                        // the caller's length hint was too small for this pair: refuse loudly instead of aligning
+                        // with a window that does not hold the band (include/agatha_amd.h: AGATHA_AMD_BAD_RESULT)
+                        if (k == 0) { La->score[pair] = INT_MIN; La->qend[pair] = -1; La->tend[pair] = -1; }
+                        alive = false;
                     }
                 }
             }

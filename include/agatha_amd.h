@@ -69,6 +69,10 @@ int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, ui
 int agatha_amd_seq_ops(void* stream, const uint8_t* d_unpacked, uint32_t* d_packed, const uint32_t* d_lens,
                        const uint32_t* d_offsets, const uint8_t* d_ops, uint32_t n_seqs);
 
+/* Result triple written for a pair whose true lengths exceed the max_*_len hints badly enough that the chosen lane
+ * group cannot hold its band: (AGATHA_AMD_BAD_RESULT, -1, -1).  Correct hints (or 0 = unknown) never produce it. */
+#define AGATHA_AMD_BAD_RESULT INT32_MIN
+
 /* Sort + align one batch.  Replaces agatha_kernel_launcher (gasal_align.cu:10-23): the agatha_sort kernel,
  * its D2H / host std::sort / H2D round trip, and agatha_kernel itself.
  * max_query_len / max_target_len: upper bounds of the lengths in this batch (0 = unknown); they only let

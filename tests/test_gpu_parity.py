@@ -131,3 +131,33 @@ def test_reverse_complement_ops(eng):
     b_.free()
     eq, _, _ = O.make_batch([_transform(q, o) for q, o in zip(qs, qops)])
     assert (pq == O.pack(eq)).all()
+
+
+def test_edge_shapes(eng):
+    """Empty-ish and ragged inputs: single pair, length-1 sequences, one side much longer, many tiny pairs."""
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
+    cases = [([b"A"], [b"A"]), ([b"A"], [b"ACGTACGTACGT" * 50]), ([b"ACGT" * 2000], [b"AC"]),
+             ([b"N" * 9], [b"N" * 17]), ([b"ACGTACGTA"], [b"ACGTACGTA"])]
+    for qs, ts in cases:
+        got = _gpu(eng, qs, ts, p)
+        exp = O.align_pairs(qs, ts, O.make_params(**p), wide=True)
+        assert all((a == b).all() for a, b in zip(got, exp)), (qs[0][:12], ts[0][:12])
+    rng = np.random.default_rng(3)
+    qs = [synth.random_seq(rng, int(n)).tobytes() for n in rng.integers(1, 40, 20000)]
+    ts = [synth.random_seq(rng, int(n)).tobytes() for n in rng.integers(1, 40, 20000)]
+    got = _gpu(eng, qs, ts, p)
+    exp = O.align_pairs(qs, ts, O.make_params(**p), wide=True, threads=8)
+    assert all((a == b).all() for a, b in zip(got, exp))
+
+
+def test_wrong_length_hint_is_refused_per_pair(eng):
+    """A batch whose hint claims short reads but holds a long pair: that pair comes back as BAD_RESULT, not garbage."""
+    import agatha_amd
+    qs, ts = synth.make_pairs(9, 4, lambda r: 6000)
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    b.max_qlen, b.max_tlen = 64, 64                  # lie: window of 8 blocks -> 16-lane groups, band needs 95
+    b.upload(); b.pack(); b.align(agatha_amd.Scores.make()); b.download(); eng.synchronize()
+    assert (b.res_host[0] == -2 ** 31).all() and (b.res_host[1] == -1).all()
+    b.free()
