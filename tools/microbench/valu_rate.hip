@@ -46,6 +46,10 @@ __global__ void __launch_bounds__(256) k(int* out, int a, int b)
             if (OP == 27) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(v[j]) : "v"(b));
             if (OP == 28) asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(v[j]) : "v"(b), "v"(a));
             if (OP == 29) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(v[j]) : "s"(b));
+            if (OP == 30) { if (j & 1) asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); else asm volatile("v_sub_u32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); }
+            if (OP == 31) { if (j & 4) asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); else asm volatile("v_sub_u32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); }
+            if (OP == 32) { if (j == 7) asm volatile("s_and_b64 %0, %0, %1" : "+s"(m64) : "s"(m2)); else asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); }
+            if (OP == 33) { if (j & 1) asm volatile("s_and_b64 %0, %0, %1" : "+s"(m64) : "s"(m2)); else asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); }
         }
     }
     int s = 0;
@@ -76,13 +80,9 @@ double run(const char* name, int waves_per_simd)
 
 int main()
 {
-    for (int w : {2, 8}) {
-        run<0>("v_add_u32", w); run<13>("v_sub_u32", w); run<29>("v_subrev s", w); run<1>("v_max_i32", w); run<22>("v_min_i32", w); run<2>("v_max3_i32", w);
-        run<3>("v_lshl_add_u32", w); run<8>("v_add3_u32", w); run<7>("v_cndmask vcc", w); run<10>("v_cndmask e64", w);
-        run<11>("v_cmp vcc", w); run<12>("v_cmp e64 sgpr", w); run<20>("cmp+cndmask", w); run<21>("add+max pair", w);
-        run<14>("v_xor_b32", w); run<15>("v_perm_b32", w); run<16>("v_bfe_u32", w); run<17>("v_mov_b32", w); run<18>("v_mad_i32_i24", w);
-        run<19>("v_add_sdwa", w); run<23>("v_bfi_b32", w); run<24>("v_and_or_b32", w); run<25>("v_max_i32_dpp", w); run<26>("v_max_i16", w);
-        run<4>("v_pk_max_i16", w); run<5>("v_pk_add_i16", w); run<27>("v_pk_sub_i16", w); run<28>("v_pk_mad_i16", w); run<6>("v_fma_f32", w);
+    for (int w : {1, 2, 3, 8}) {
+        run<0>("v_add_u32", w); run<1>("v_max_i32", w); run<30>("sub/max alt", w); run<31>("4sub+4max", w);
+        run<32>("7max+1salu", w); run<33>("4max+4salu", w);
     }
     return 0;
 }
