@@ -356,6 +356,7 @@ void agatha_model_exactband(const char *qs, int Q, const char *rs, int R, const 
         int diag = Hrow[0];
         Hrow[0] = hleft;
         int jlo = imax(0, i - w), jhi = imin(R - 1, i + w);
+        if (jlo > jhi) continue;               /* the band has left the matrix on this row */
         if (jlo > 0) { diag = Hrow[jlo]; }
         for (int j = jlo; j <= jhi; j++) {
             int up = Hrow[j + 1];

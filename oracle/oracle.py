@@ -26,7 +26,7 @@ def make_params(m=2, x=4, q=4, r=2, s=3, z=400, w=751):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("agatha_oracle.c", "agatha_lanes_model.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("agatha_oracle.c", "agatha_lanes_model.c", "ksw_style_avx2.c", "Makefile")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     return _LIB
@@ -48,6 +48,9 @@ def lib():
         _lib.agatha_lanes_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int,
                                                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _lib.agatha_lanes_batch.restype = None
+        _lib.ksw_style_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p,
+                                                            C.c_void_p, C.POINTER(C.c_int)]
+        _lib.ksw_style_batch.restype = None
     return _lib
 
 
@@ -95,6 +98,20 @@ def lanes_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, G, S, threads=1):
     if rc.value:
         raise ValueError("G*S too small for this band")
     return out[0], out[1], out[2]
+
+
+def ksw_style_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, threads=1):
+    """Anti-diagonal AVX2 CPU kernel (oracle/ksw_style_avx2.c), exact-band semantics; returns (score, qend, tend, n_fallback)
+    where n_fallback counts pairs outside the int16 domain that went through the scalar exact-band model instead."""
+    n = len(qlen)
+    qbuf = np.ascontiguousarray(qbuf, np.uint8)
+    tbuf = np.ascontiguousarray(tbuf, np.uint8)
+    arrs = [np.ascontiguousarray(a, np.uint32) for a in (qoff, toff, qlen, tlen)]
+    out = np.zeros((3, n), np.int32)
+    fb = C.c_int(0)
+    lib().ksw_style_batch(qbuf.ctypes.data, tbuf.ctypes.data, *[a.ctypes.data for a in arrs], n, C.byref(params),
+                          int(threads), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, C.byref(fb))
+    return out[0], out[1], out[2], fb.value
 
 
 def align_pairs(queries, targets, params, **kw):

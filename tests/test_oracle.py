@@ -75,3 +75,31 @@ def test_nominal_cells_formula():
     L, w = 10000, 751
     assert O.nominal_cells(L, L, w) == L * (2 * w + 1) - w * (w + 1) == 14465248
     assert O.nominal_cells_np([L], [L], w) == 14465248
+
+
+def test_ksw_style_avx2_equals_exact_band_model():
+    """The SIMD CPU baseline (oracle/ksw_style_avx2.c) is bit-identical to the scalar exact-band model."""
+    rng = np.random.default_rng(8)
+    for _ in range(80):
+        w = int(rng.choice([0, 1, 5, 8, 9, 16, 33, 64, 100, 751]))
+        P = O.make_params(m=int(rng.choice([1, 2, 3])), x=4, q=int(rng.choice([2, 4, 6])), r=int(rng.choice([1, 2])),
+                          z=int(rng.choice([-1, 0, 40, 400])), w=w)
+        e = float(rng.uniform(0, 0.15))
+        qs, ts = synth.make_pairs(int(rng.integers(1 << 30)), 12, lambda r: int(np.exp(r.uniform(0, np.log(2000)))),
+                                  e, e, e, n_rate=0.01)
+        if rng.random() < 0.4:
+            ts = [t[: max(1, len(t) // 3)] for t in ts]
+        qb, qo, ql = O.make_batch(qs)
+        tb, to, tl = O.make_batch(ts)
+        a = O.align_batch(qb, tb, qo, to, ql, tl, P, model=O.MODEL_EXACTBAND)
+        b = O.ksw_style_batch(qb, tb, qo, to, ql, tl, P, threads=2)
+        assert all((x == y).all() for x, y in zip(a, b[:3]))
+
+
+def test_ksw_style_matches_reference_vectors_at_baseline_band():
+    for g in load_ref_vectors():
+        if g["params"]["w"] < 500:
+            continue
+        r = O.ksw_style_batch(g["qbatch"], g["tbatch"], g["qoff"], g["toff"], g["qlen"], g["tlen"],
+                              O.make_params(**g["params"]), threads=4)
+        assert all((x == y).all() for x, y in zip(r[:3], g["expect"])), g["name"]
