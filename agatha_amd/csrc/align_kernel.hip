@@ -52,6 +52,33 @@ __device__ __forceinline__ int group_max(int v, int lane)
     return v;
 }
 
+// the same for eight values at once: all cross-row ds_bpermutes are issued before the first one is waited for
+template <int G>
+__device__ __forceinline__ void group_max8(int (&v)[8], int lane)
+{
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+        v[x] = imax(v[x], __builtin_amdgcn_update_dpp(INT_MIN, v[x], 0x121, 0xf, 0xf, true));
+        v[x] = imax(v[x], __builtin_amdgcn_update_dpp(INT_MIN, v[x], 0x122, 0xf, 0xf, true));
+        v[x] = imax(v[x], __builtin_amdgcn_update_dpp(INT_MIN, v[x], 0x124, 0xf, 0xf, true));
+        v[x] = imax(v[x], __builtin_amdgcn_update_dpp(INT_MIN, v[x], 0x128, 0xf, 0xf, true));
+    }
+    if (G >= 32) {
+        int o[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) o[x] = lane_read(v[x], lane ^ 16);
+#pragma unroll
+        for (int x = 0; x < 8; x++) v[x] = imax(v[x], o[x]);
+    }
+    if (G >= 64) {
+        int o[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) o[x] = lane_read(v[x], lane ^ 32);
+#pragma unroll
+        for (int x = 0; x < 8; x++) v[x] = imax(v[x], o[x]);
+    }
+}
+
 template <int GS> struct KeyBits {          // smallest K with 2^K >= 8 * (GS + 2)
     static constexpr int value = (8 * (GS + 2) <= 128) ? 7 : (8 * (GS + 2) <= 256) ? 8 : (8 * (GS + 2) <= 512) ? 9
                                : (8 * (GS + 2) <= 1024) ? 10 : (8 * (GS + 2) <= 2048) ? 11 : (8 * (GS + 2) <= 4096) ? 12 : 13;
@@ -80,20 +107,29 @@ __device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge,
 //   rh      H(row, column left of the block) for the 8 rows                    (in)
 //   e       E(row, first column) in, E(row, column right of the block) out     (in/out)
 //   oh      H(row, last column) out
-// All scores are carried pre-shifted (H << K, and so are match/mismatch/gap constants): max/add commute with the
-// scaling, and the packed anti-diagonal key (H << K) + relative column then costs a single three-operand add.
+// Substitution scores come from a per-(lane, slot) PROFILE in LDS: for the 8 reference bases of this column block,
+// one row of 8 signed bytes per query-base class (A, C, G, T, N), built once when the column block starts.  A row of
+// the block then costs one ds_read_b64 and each cell's "score + diagonal" is a single v_add_u32_sdwa (sign-extended
+// byte operand) instead of compare + select + add.  Pairs that contain letters outside ACGTN (flagged by
+// exotic_kernel) take the compare path (use_cmp, wave-uniform), which also carries the N rule of
+// gasal_kernels.h:48-50.
 // MASKED: per-cell band test of boundary blocks and the row limit of the last row block, as EXEC masks
-//         built once per block (km: one lane mask per cell diagonal jl-il, rm: one per row).
-// any_n : wave-uniform: some lane's words hold an N (score -1, gasal_kernels.h:48-50); patched per row, rarely.
+//         built once per block (km: one lane mask per cell diagonal jl-il).
 template <bool MASKED, int K>
 __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, const int (&rh)[8], int (&e)[8],
                                          int (&oh)[8], int (&A)[15], uint32_t qword, uint32_t rword,
-                                         int va, int vnb, int gapoe, int ge, int crel0, int nrows, int tu, int tl,
-                                         int t0, bool any_n)
+                                         const uint2* __restrict__ prof, int va, int vnb, int gapoe, int ge,
+                                         int crel0, int nrows, int tu, int tl, int t0, bool use_cmp)
 {
-    uint32_t rb[8];
+    // all eight profile rows are requested up front: their LDS latency then hides behind the mask set-up and the
+    // first rows instead of stalling every row (class of a query base = bits 3..1 of its code:
+    // A(1)->0 C(3)->1 T(4)->2 G(7)->3 N(14)->7)
+    uint2 pw[8];
 #pragma unroll
-    for (int jl = 0; jl < 8; jl++) rb[jl] = (rword >> (28 - 4 * jl)) & 15u;
+    for (int il = 0; il < 4; il++) pw[il] = prof[((qword >> (29 - 4 * il)) & 7u) * 64u];
+    int cj[8];
+#pragma unroll
+    for (int jl = 0; jl < 8; jl++) cj[jl] = crel0 + jl;
     unsigned long long km[15];
     if (MASKED) {
         // Away from the matrix corners an edge block has tu == t0 (upper edge) or tl == t0 (lower edge), t0 = w - 8W,
@@ -115,20 +151,30 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
     }
 #pragma unroll
     for (int il = 0; il < 8; il++) {
-        if (!MASKED || il < nrows) {            // rows past the end of the query exist only in the last row block
-            const uint32_t qb = (qword >> (28 - 4 * il)) & 15u;
-            int t[8];
+        if (il == 1) {                          // second half of the profile rows: requested three rows ahead of use
 #pragma unroll
-            for (int jl = 0; jl < 8; jl++) {
-                const int sc = (qb == rb[jl]) ? va : vnb;
-                const int d = (jl == 0) ? ((il == 0) ? corner : rh[il - 1]) : h[jl - 1];
-                t[jl] = sc + d;
-            }
-            if (any_n) {      // wave-uniform and rare: some lane's words hold an N (score -1, gasal_kernels.h:48-50)
+            for (int i2 = 4; i2 < 8; i2++) pw[i2] = prof[((qword >> (29 - 4 * i2)) & 7u) * 64u];
+        }
+        if (!MASKED || il < nrows) {            // rows past the end of the query exist only in the last row block
+            int t[8];
+            if (use_cmp) {
+                const uint32_t qb = (qword >> (28 - 4 * il)) & 15u;
 #pragma unroll
                 for (int jl = 0; jl < 8; jl++) {
+                    const uint32_t rb = (rword >> (28 - 4 * jl)) & 15u;
+                    int sc = (qb == rb) ? va : vnb;
+                    sc = (qb == N_VALUE || rb == N_VALUE) ? -1 : sc;
                     const int d = (jl == 0) ? ((il == 0) ? corner : rh[il - 1]) : h[jl - 1];
-                    if (qb == N_VALUE || rb[jl] == N_VALUE) t[jl] = d - (1 << K);
+                    t[jl] = sc + d;
+                }
+            } else {
+                const uint2 w = pw[il];
+#pragma unroll
+                for (int jl = 0; jl < 8; jl++) {
+                    const uint32_t word = (jl & 1) ? w.y : w.x;            // even columns in .x, odd in .y
+                    const int sc = (int)(int8_t)((word >> (8 * (3 - (jl >> 1)))) & 0xffu);
+                    const int d = (jl == 0) ? ((il == 0) ? corner : rh[il - 1]) : h[jl - 1];
+                    t[jl] = sc + d;
                 }
             }
             // every diagonal term is taken from the PREVIOUS row's H: pin them before H is overwritten
@@ -143,7 +189,7 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
                     f[jl] = imax(tg, f[jl] - ge);
                     ev = imax(tg, ev - ge);
                     h[jl] = hn;
-                    A[il + jl] = imax(A[il + jl], hn + crel0 + jl);      // one v_add3: low K bits of hn are zero
+                    A[il + jl] = imax(A[il + jl], (int)(((uint32_t)hn << K) + (uint32_t)cj[jl]));
                 }
             }
             oh[il] = h[7]; e[il] = ev;
@@ -152,6 +198,28 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
     // p[1] = h[0] of the last processed row (agatha_kernel.h:28).  A block with fewer than 8 rows is the last
     // block of its column (q == pql-1), after which the corner is never read again, so row 7 is always right.
     corner = rh[7];
+}
+
+// Score profile of one column block: rows of 8 signed bytes (even columns in .x, odd in .y, column 0/1 in the top
+// byte) for the query-base classes 0..3 = A, C, T, G and 7 = N.  SWAR on the 8 packed reference codes.
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t R, uint32_t code4)       // 0xFF in every byte where R == code
+{
+    const uint32_t X = R ^ code4;
+    const uint32_t ne = ((X + 0x7F7F7F7Fu) & 0x80808080u) >> 7;                // 1 where the byte differs (codes <= 15)
+    return (ne ^ 0x01010101u) * 0xFFu;
+}
+__device__ __forceinline__ void build_profile(uint2* __restrict__ prof, uint32_t rword, int a, int b)
+{
+    const uint32_t Re = (rword >> 4) & 0x0F0F0F0Fu, Ro = rword & 0x0F0F0F0Fu;  // columns 0,2,4,6 / 1,3,5,7
+    const uint32_t A4 = ((uint32_t)a & 0xFFu) * 0x01010101u, NB4 = ((uint32_t)(-b) & 0xFFu) * 0x01010101u;
+    const uint32_t BMe = NB4 | eq_bytes(Re, 0x0E0E0E0Eu), BMo = NB4 | eq_bytes(Ro, 0x0E0E0E0Eu);   // -b, or -1 where ref is N
+    const uint32_t codes[4] = {0x01010101u, 0x03030303u, 0x04040404u, 0x07070707u};              // A C T G
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t me = eq_bytes(Re, codes[c]), mo = eq_bytes(Ro, codes[c]);
+        prof[c * 64] = make_uint2((A4 & me) | (BMe & ~me), (A4 & mo) | (BMo & ~mo));
+    }
+    prof[7 * 64] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);                                          // query N: always -1
 }
 
 __device__ __forceinline__ bool word_has_n(uint32_t v)
@@ -169,20 +237,19 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
     constexpr int GS = G * S;
     constexpr int K = KeyBits<GS>::value;
     constexpr int KMASK = (1 << K) - 1;
-    constexpr int NEGK = NEG_INF2 * (1 << K);
+    constexpr int NEGK = NEG_INF2;
 
+    __shared__ uint2 s_prof[4 * S * 8 * 64];      // [wave][slot][class][lane] score profiles (block8x8)
     const int lane = threadIdx.x & 63;
+    uint2* const prof0 = s_prof + (threadIdx.x >> 6) * (S * 8 * 64) + lane;
     const int k = lane & (G - 1);                 // lane inside the group
     const int gbase = lane & ~(G - 1);            // first lane of the group
     const int left_lane = gbase | ((k + G - 1) & (G - 1));
 
-    // everything that is a SCORE lives in the shifted domain (x << K); lengths, positions and z stay plain
-    const int gapoe = (P.gap_open + P.gap_extend) << K, ge = P.gap_extend << K;
+    const int gapoe = P.gap_open + P.gap_extend, ge = P.gap_extend;
     const int sw = P.slice_width, z = P.z_threshold, w = P.band_width;
     const int W = (w + 7) >> 3;
-    int va = P.match << K, vnb = -(P.mismatch << K);   // kept in VGPRs: both arms of the score select
-    int vgapoe = gapoe, vge = ge;                      // VGPR copies: v_sub with two VGPR operands issues in half the
-    asm volatile("" : "+v"(va), "+v"(vnb), "+v"(vgapoe), "+v"(vge));   // cycles of the SGPR-operand form (tools/microbench)
+    int va = P.match, vnb = -P.mismatch;               // kept in VGPRs: both arms of the score select (compare path)
 
     // ---- per-pair state (uniform inside a group) ----
     int Q = 0, R = 0, pql = 0, prl = 0, total = 0, lim = 0, pair = 0;
@@ -192,18 +259,19 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
     gptr_t pq = nullptr;
     gptr_t pt = nullptr;
     int i = 0, y = 0, ss = 0, se = 0, cb_prev = 0;
-    bool alive = false, exhausted = false, final_step = false;
+    bool alive = false, exhausted = false, final_step = false, use_cmp_pair = false;
     int best = 0, best_t = 0, best_q = 0;
 
     // ---- per-lane state ----
     int rcur[S], corner[S];
     int h[S][8], f[S][8];
     uint32_t rword[S];
+    uint32_t qcur[S];                              // packed query word of the row block each slot works on this step
     int xh[S + 1][8], xe[S + 1][8], xr[S + 1];   // hand-off: X[s] feeds slot s, X[S] leaves slot S-1
     int A[15];
 
 #pragma unroll
-    for (int s = 0; s < S; s++) { rcur[s] = 0; corner[s] = 0; rword[s] = 0;
+    for (int s = 0; s < S; s++) { rcur[s] = 0; corner[s] = 0; rword[s] = 0; qcur[s] = 0;
 #pragma unroll
         for (int m = 0; m < 8; m++) { h[s][m] = 0; f[s][m] = 0; } }
 #pragma unroll
@@ -227,6 +295,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                     Q = (int)La->qlens[pair]; R = (int)La->tlens[pair];
                     pq = (gptr_t)(La->packed_q + (La->qoffs[pair] >> 3));
                     pt = (gptr_t)(La->packed_t + (La->toffs[pair] >> 3));
+                    use_cmp_pair = La->force_cmp || (La->exotic[pair] != 0);
                     pql = (Q + 7) >> 3; prl = (R + 7) >> 3;
                     total = prl + pql - 1; lim = Q + R - 1;
                     best = 0; best_t = 0; best_q = 0;
@@ -238,6 +307,9 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                         rcur[s] = k * S + s;
                         init_col(rcur[s], R, w, gapoe, ge, NEGK, h[s], f[s], corner[s]);
                         rword[s] = (rcur[s] < prl) ? pt[rcur[s]] : 0xEEEEEEEEu;
+                        build_profile(prof0 + s * (8 * 64), rword[s], P.match, P.mismatch);
+                        const int q0 = 0 - rcur[s];                      // row block of step 0 (only column block 0 has one)
+                        qcur[s] = (q0 >= 0 && q0 < pql) ? pq[q0] : 0u;
                     }
 #pragma unroll
                     for (int s = 0; s <= S; s++) xr[s] = -2;
@@ -267,14 +339,23 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
             for (int x = 0; x < 7; x++) A[x] = __builtin_elementwise_sub_sat(A[x], delta);
         }
 
+        // Which slots leave their column after this step is known now.  Right after a slot's block the packed words
+        // its NEXT step needs are requested into the registers that just became free, so a whole step hides the loads.
+        bool adv[S];
+        bool any_adv = false;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            adv[s] = alive && (i + 1 - rcur[s] > imin(pql - 1, rcur[s] + W));
+            any_adv |= adv[s];
+        }
+
 #pragma unroll
         for (int s = S - 1; s >= 0; s--) {
             const int r = rcur[s], q = i - r;
             const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
             const bool active = alive && !final_step && r < prl && q >= cs && q <= ce && r >= ss && r <= se;
             xr[s + 1] = active ? r : -2;
-            uint32_t qword = 0;
-            if (active) qword = pq[q];
+            const uint32_t qword = qcur[s];
             const uint32_t rw = rword[s];
             const int nrows = imin(8, Q - 8 * q);
             const bool boundary = (q == cs) || (q == ce);               // agatha_kernel.h:243
@@ -308,8 +389,17 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                 const int crel0 = 8 * r - cb;
                 // Edge blocks (band test) exist on every anti-diagonal, so a mask-free variant would rarely run for
                 // a whole wave; Ns are rare (padding of the last column block, occasional N in a read).
-                const bool any_n = __any(word_has_n(qword) || word_has_n(rw));
-                block8x8<true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, va, vnb, vgapoe, vge, crel0, nrows, tu, tl, w - 8 * W, any_n);
+                const bool use_cmp = __any(use_cmp_pair);     // some pair of this wave has letters outside ACGTN
+                block8x8<true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, prof0 + s * (8 * 64),
+                                  va, vnb, gapoe, ge, crel0, nrows, tu, tl, w - 8 * W, use_cmp);
+            }
+            {   // prefetch for step i + 1 (the column's own words are dead from here on if it advances)
+                const int rn = adv[s] ? r + GS : r;
+                const int qn = i + 1 - rn;
+                uint32_t qv = 0u;
+                if (alive && qn >= 0 && qn < pql) qv = pq[qn];
+                qcur[s] = qv;
+                if (adv[s]) rword[s] = (rn < prl) ? pt[rn] : 0xEEEEEEEEu;
             }
         }
         // X[S] of the left neighbour lane becomes X[0]
@@ -321,7 +411,8 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
         bool stopped = false;
         int vred[8];
 #pragma unroll
-        for (int x = 0; x < 8; x++) vred[x] = group_max<G>(A[x], lane);
+        for (int x = 0; x < 8; x++) vred[x] = A[x];
+        group_max8<G>(vred, lane);
         // Fast path (wave-uniform): every anti-diagonal of this step is non-empty, inside the pair, and within z of the
         // running maximum, so z-drop cannot fire (agatha_kernel.h:304 needs best - H > z + l*ge >= z) and only the
         // running maximum and its position have to be advanced.
@@ -354,7 +445,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                     else if (c >= best_t && (d - c) >= best_q) {
                         const int tlen = c - best_t, qlen = (d - c) - best_q;
                         const int l = tlen > qlen ? tlen - qlen : qlen - tlen;
-                        if (z >= 0 && best - H > z + l * P.gap_extend) stopped = true;
+                        if (z >= 0 && best - H > z + l * ge) stopped = true;
                     }
                 }
             }
@@ -369,10 +460,6 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
         cb_prev = cb;
 
         // slots whose column block has left the band move on to column r + G*S
-        bool adv[S];
-        bool any_adv = false;
-#pragma unroll
-        for (int s = 0; s < S; s++) { adv[s] = alive && (i + 1 - rcur[s] > imin(pql - 1, rcur[s] + W)); any_adv |= adv[s]; }
         if (__any(any_adv)) {
 #pragma unroll
             for (int s = 0; s < S; s++) {
@@ -380,7 +467,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                     const int rn = rcur[s] + GS;
                     rcur[s] = rn;
                     init_col(rn, R, w, gapoe, ge, NEGK, h[s], f[s], corner[s]);
-                    rword[s] = (rn < prl) ? pt[rn] : 0xEEEEEEEEu;
+                    build_profile(prof0 + s * (8 * 64), rword[s], P.match, P.mismatch);
                 }
             }
         }
@@ -477,6 +564,64 @@ pack_kernel(const uint4* __restrict__ in16, uint2* __restrict__ out8, uint32_t n
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Prepass: flag the pairs whose sequences hold a letter outside {A, C, G, T, N} (any case).  The alignment kernel's
+// score profile only has rows for those five classes; flagged pairs use its compare path.  One wave per pair.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zero_nibbles(uint32_t x)     // 0x8 in every nibble of x that is zero
+{
+    return (x - 0x11111111u) & ~x & 0x88888888u;
+}
+__device__ __forceinline__ bool word_is_plain(uint32_t v)
+{
+    const uint32_t ok = zero_nibbles(v ^ 0x11111111u) | zero_nibbles(v ^ 0x33333333u) | zero_nibbles(v ^ 0x44444444u) |
+                        zero_nibbles(v ^ 0x77777777u) | zero_nibbles(v ^ 0xEEEEEEEEu);
+    return ok == 0x88888888u;
+}
+// NOTE zero_nibbles() can raise a false "zero" flag in a nibble ABOVE a true zero nibble (borrow); that only ever
+// makes word_is_plain() report plain for a word that has an exotic nibble directly above a plain one, so the test is
+// done per nibble instead where it matters:
+__device__ __forceinline__ bool word_is_plain_exact(uint32_t v)
+{
+    bool ok = true;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+        const uint32_t c = (v >> (4 * k2)) & 15u;
+        ok = ok && ((0x409Au >> c) & 1u);          // bits 1, 3, 4, 7, 14
+    }
+    return ok;
+}
+
+__global__ void __launch_bounds__(256)
+exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__ packed_t,
+              const uint32_t* __restrict__ qlens, const uint32_t* __restrict__ tlens,
+              const uint32_t* __restrict__ qoffs, const uint32_t* __restrict__ toffs, uint8_t* __restrict__ exotic, int n)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < n; p += nwaves) {
+        bool plain = true;
+        const uint32_t* a = packed_q + (qoffs[p] >> 3);
+        const uint32_t na = (qlens[p] + 7u) >> 3;
+        for (uint32_t i = lane; i < na; i += 64u) plain = plain && word_is_plain_exact(a[i]);
+        const uint32_t* b = packed_t + (toffs[p] >> 3);
+        const uint32_t nb = (tlens[p] + 7u) >> 3;
+        for (uint32_t i = lane; i < nb; i += 64u) plain = plain && word_is_plain_exact(b[i]);
+        const bool all_plain = __all(plain);
+        if (lane == 0) exotic[p] = all_plain ? 0 : 1;
+    }
+}
+
+hipError_t launch_exotic(const AlignLaunch& L, hipStream_t st)
+{
+    int blocks = (L.n + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(exotic_kernel, dim3(blocks), dim3(256), 0, st, L.packed_q, L.packed_t, L.qlens, L.tlens, L.qoffs,
+                       L.toffs, L.exotic, L.n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Per-sequence reverse / complement (replaces gasal_reversecomplement_kernel, pack_rc_seqs.h:56-212, which the
 // reference runs in place on the packed words with one thread per pair).  Here the packed words of a sequence
 // whose op code is non-zero are simply re-derived from the unpacked ASCII that is still in HBM: one wave per
@@ -540,7 +685,8 @@ static hipError_t launch_align_t(const AlignLaunch& L, hipStream_t st)
     // enough groups for every pair, capped by what the chip can keep resident (2 waves/SIMD = 8 waves/CU)
     const int groups_per_block = (256 / 64) * (64 / G);
     int blocks = (L.n + groups_per_block - 1) / groups_per_block;
-    const int max_blocks = L.num_cus * 2;
+    int max_blocks = L.num_cus * (S <= 3 ? 2 : 1);
+    if (L.max_blocks_override > 0) max_blocks = L.max_blocks_override;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((align_kernel<G, S>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);

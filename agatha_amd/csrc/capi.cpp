@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -68,7 +69,7 @@ int agatha_amd_max_band(void) { return (agatha::max_window_blocks() - 1) * 8; }
 size_t agatha_amd_workspace_bytes(uint32_t max_n_alns)
 {
     return round_up(sizeof(uint32_t) * (size_t)max_n_alns) + round_up(sizeof(uint32_t) * kBuckets) + kAlign +
-           round_up(sizeof(agatha::AlignLaunch));
+           round_up(sizeof(agatha::AlignLaunch)) + round_up((size_t)max_n_alns);
 }
 
 int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, uint32_t* d_packed)
@@ -121,7 +122,8 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     uint32_t* order = (uint32_t*)ws;             ws += round_up(sizeof(uint32_t) * (size_t)n_alns);
     uint32_t* hist = (uint32_t*)ws;              ws += round_up(sizeof(uint32_t) * kBuckets);
     unsigned int* queue = (unsigned int*)ws;     ws += kAlign;
-    agatha::AlignLaunch* rec = (agatha::AlignLaunch*)ws;
+    agatha::AlignLaunch* rec = (agatha::AlignLaunch*)ws;   ws += round_up(sizeof(agatha::AlignLaunch));
+    uint8_t* exotic = (uint8_t*)ws;
 
     HIPCHK(agatha::launch_sort(d_query_lens, d_target_lens, (int)n_alns, hist, kBuckets, order, st));
 
@@ -132,6 +134,10 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.score = d_aln_score; L.qend = d_query_batch_end; L.tend = d_target_batch_end;
     L.p = {sc->match, sc->mismatch, sc->gap_open, sc->gap_extend, sc->slice_width, sc->z_threshold, sc->band_width};
     L.num_cus = num_cus();
+    L.exotic = exotic;
+    L.force_cmp = (sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
+    HIPCHK(agatha::launch_exotic(L, st));
+    { const char* e = getenv("AGATHA_AMD_MAX_BLOCKS"); L.max_blocks_override = e ? atoi(e) : 0; }
     L.self_dev = rec;
     HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record + queue head reset, stream-ordered
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));

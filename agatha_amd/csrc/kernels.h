@@ -12,9 +12,12 @@ struct AlignLaunch {
     const uint32_t *packed_q, *packed_t, *qlens, *tlens, *qoffs, *toffs, *order;
     int n;
     unsigned int* queue;
+    uint8_t* exotic;               // per pair: 1 = holds letters outside ACGTN (compare path)
+    int force_cmp;                 // 1 = scores do not fit the byte profile: compare path for every pair
     int32_t *score, *qend, *tend;
     AlignParams p;
     int num_cus;
+    int max_blocks_override;       // > 0: cap of the persistent grid (tuning knob, AGATHA_AMD_MAX_BLOCKS)
     const AlignLaunch* self_dev;   // device copy of this record (lives in the workspace)
 };
 
@@ -23,6 +26,7 @@ hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int
 int max_window_blocks();
 int key_bits_for_window(int window_blocks);
 // writes L into *rec on the device (by-value kernel argument: no host-memory lifetime to care about) and zeroes *L.queue
+hipError_t launch_exotic(const AlignLaunch& L, hipStream_t st);
 hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st);
 hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint32_t* hist, uint32_t nbuckets,
                        uint32_t* order, hipStream_t st);

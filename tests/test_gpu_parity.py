@@ -161,3 +161,24 @@ def test_wrong_length_hint_is_refused_per_pair(eng):
     b.upload(); b.pack(); b.align(agatha_amd.Scores.make()); b.download(); eng.synchronize()
     assert (b.res_host[0] == -2 ** 31).all() and (b.res_host[1] == -1).all()
     b.free()
+
+
+def test_letters_outside_acgtn(eng):
+    """Any other letter only matches a letter with the same low nibble (reference: `ASCII & 0xF`); pairs holding such
+    letters take the kernel's compare path, the others the score-profile path -- mixed in one batch here."""
+    rng = np.random.default_rng(77)
+    qs, ts = synth.make_pairs(31, 48, lambda r: int(r.integers(50, 1500)), 0.03, 0.03, 0.03, n_rate=0.01)
+    alphabet = np.frombuffer(b"RYKMBDHVryswU*", dtype=np.uint8)
+    qs2, ts2 = [], []
+    for k, (q, t) in enumerate(zip(qs, ts)):
+        q, t = np.frombuffer(q, np.uint8).copy(), np.frombuffer(t, np.uint8).copy()
+        if k % 3 == 0:                      # a third of the pairs get exotic letters on one or both sides
+            q[rng.random(q.size) < 0.02] = rng.choice(alphabet)
+            if k % 2 == 0:
+                t[rng.random(t.size) < 0.02] = rng.choice(alphabet)
+        qs2.append(q.tobytes()); ts2.append(t.tobytes())
+    for p in (dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751), dict(m=1, x=4, q=6, r=2, s=3, z=50, w=33),
+              dict(m=200, x=300, q=4, r=2, s=3, z=400, w=100)):      # last: scores that do not fit the byte profile
+        got = _gpu(eng, qs2, ts2, p)
+        exp = O.align_pairs(qs2, ts2, O.make_params(**p), wide=True, threads=4)
+        assert all((a == b).all() for a, b in zip(got, exp)), p
