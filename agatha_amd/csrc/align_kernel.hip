@@ -28,7 +28,7 @@
 
 namespace agatha {
 
-#define NEG_INF2 (-16384)   // SHRT_MIN/2: the reference's -infinity (gasal_kernels.h:39); kernels use NEG_INF2 << K
+#define NEG_INF2 (-16384)   // SHRT_MIN/2: the reference's -infinity (gasal_kernels.h:39)
 #define N_VALUE 14u         // 'N' & 0xF (AGAThA/Makefile:4)
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -38,21 +38,8 @@ __device__ __forceinline__ int imax3(int a, int b, int c) { return imax(imax(a, 
 // value of lane `src` (absolute lane id) -- ds_bpermute_b32, no LDS storage involved
 __device__ __forceinline__ int lane_read(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
 
-// max over the G lanes of a group, result in every lane
-template <int G>
-__device__ __forceinline__ int group_max(int v, int lane)
-{
-    // rotations inside a 16-lane DPP row: row_ror:1,2,4,8
-    v = imax(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x121, 0xf, 0xf, true));
-    v = imax(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x122, 0xf, 0xf, true));
-    v = imax(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x124, 0xf, 0xf, true));
-    v = imax(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x128, 0xf, 0xf, true));
-    if (G >= 32) v = imax(v, lane_read(v, lane ^ 16));
-    if (G >= 64) v = imax(v, lane_read(v, lane ^ 32));
-    return v;
-}
-
-// the same for eight values at once: all cross-row ds_bpermutes are issued before the first one is waited for
+// max over the G lanes of a group of eight values at once, result in every lane: DPP row rotations inside a 16-lane
+// row, then all cross-row ds_bpermutes are issued before the first one is waited for
 template <int G>
 __device__ __forceinline__ void group_max8(int (&v)[8], int lane)
 {
@@ -85,7 +72,6 @@ template <int GS> struct KeyBits {          // smallest K with 2^K >= 8 * (GS + 
 };
 
 // initial column state of column block r: H(-1, c), F(0, c)  (agatha_kernel.h:133-148, 207-215)
-// gapoe, ge and neg are already in the shifted score domain.
 __device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge, int neg, int (&h)[8], int (&f)[8], int& corner)
 {
 #pragma unroll
@@ -220,12 +206,6 @@ __device__ __forceinline__ void build_profile(uint2* __restrict__ prof, uint32_t
         prof[c * 64] = make_uint2((A4 & me) | (BMe & ~me), (A4 & mo) | (BMo & ~mo));
     }
     prof[7 * 64] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);                                          // query N: always -1
-}
-
-__device__ __forceinline__ bool word_has_n(uint32_t v)
-{
-    const uint32_t x = v ^ 0xEEEEEEEEu;            // a zero nibble <=> an N
-    return ((x - 0x11111111u) & ~x & 0x88888888u) != 0u;
 }
 
 template <int G, int S>
@@ -567,20 +547,7 @@ pack_kernel(const uint4* __restrict__ in16, uint2* __restrict__ out8, uint32_t n
 // Prepass: flag the pairs whose sequences hold a letter outside {A, C, G, T, N} (any case).  The alignment kernel's
 // score profile only has rows for those five classes; flagged pairs use its compare path.  One wave per pair.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t zero_nibbles(uint32_t x)     // 0x8 in every nibble of x that is zero
-{
-    return (x - 0x11111111u) & ~x & 0x88888888u;
-}
 __device__ __forceinline__ bool word_is_plain(uint32_t v)
-{
-    const uint32_t ok = zero_nibbles(v ^ 0x11111111u) | zero_nibbles(v ^ 0x33333333u) | zero_nibbles(v ^ 0x44444444u) |
-                        zero_nibbles(v ^ 0x77777777u) | zero_nibbles(v ^ 0xEEEEEEEEu);
-    return ok == 0x88888888u;
-}
-// NOTE zero_nibbles() can raise a false "zero" flag in a nibble ABOVE a true zero nibble (borrow); that only ever
-// makes word_is_plain() report plain for a word that has an exotic nibble directly above a plain one, so the test is
-// done per nibble instead where it matters:
-__device__ __forceinline__ bool word_is_plain_exact(uint32_t v)
 {
     bool ok = true;
 #pragma unroll
@@ -602,10 +569,10 @@ exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict_
         bool plain = true;
         const uint32_t* a = packed_q + (qoffs[p] >> 3);
         const uint32_t na = (qlens[p] + 7u) >> 3;
-        for (uint32_t i = lane; i < na; i += 64u) plain = plain && word_is_plain_exact(a[i]);
+        for (uint32_t i = lane; i < na; i += 64u) plain = plain && word_is_plain(a[i]);
         const uint32_t* b = packed_t + (toffs[p] >> 3);
         const uint32_t nb = (tlens[p] + 7u) >> 3;
-        for (uint32_t i = lane; i < nb; i += 64u) plain = plain && word_is_plain_exact(b[i]);
+        for (uint32_t i = lane; i < nb; i += 64u) plain = plain && word_is_plain(b[i]);
         const bool all_plain = __all(plain);
         if (lane == 0) exotic[p] = all_plain ? 0 : 1;
     }
