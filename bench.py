@@ -47,11 +47,13 @@ def effective_cpus():
     return max(1, n)
 
 
-def cpu_baseline(O, qb, tb, qo, to, ql, tl, params, w, budget_s=12.0):
+def cpu_baseline(qb, tb, qo, to, ql, tl, scoring, w, budget_s=12.0):
     """CPU baseline on the GPU box's own host cores, bounded sample of the same batch, OpenMP over pairs:
     the anti-diagonal AVX2 int16 kernel oracle/ksw_style_avx2.c (own code in the manner of minimap2's ksw_extz2_sse,
     which is not available here) and, beside it, the scalar C oracle.  Both are "port" (not the reference's own code:
     the reference has no CPU path)."""
+    from oracle import oracle as O          # the ONLY place bench.py touches oracle/: the reported CPU baseline
+    params = O.make_params(**scoring)
     cores = effective_cpus()
     n = len(ql)
 
@@ -109,7 +111,7 @@ def main():
         print(f"[bench] note: WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
 
     import agatha_amd
-    from oracle import oracle as O, synth        # generators + the cpu_baseline leg only
+    from agatha_amd import workload
 
     eng = agatha_amd.Engine(local_rank)
     stream = None
@@ -118,11 +120,11 @@ def main():
     W_BAND, Z = 751, 400
     scores = agatha_amd.Scores.make(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND)
 
-    qs, ts = synth.cfg_c1(n=a.pairs, seed=0xA6A70001 + rank)
-    qb, qo, ql = O.make_batch(qs)
-    tb, to, tl = O.make_batch(ts)
+    qs, ts = workload.cfg_c1(n=a.pairs, seed=0xA6A70001 + rank)
+    qb, qo, ql = workload.make_batch(qs)
+    tb, to, tl = workload.make_batch(ts)
     del qs, ts
-    cells = O.nominal_cells_np(ql, tl, W_BAND)
+    cells = workload.nominal_cells_total(ql, tl, W_BAND)
     abytes = algorithmic_bytes(ql, tl)
 
     b = eng.batch(qb, tb, qo, to, ql, tl)
@@ -219,8 +221,7 @@ def main():
                               "ops_per_cell": OPS_PER_CELL},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(O, qb, tb, qo, to, ql, tl,
-                                               O.make_params(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND), W_BAND)
+            out["cpu_baseline"] = cpu_baseline(qb, tb, qo, to, ql, tl, dict(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND), W_BAND)
         print(json.dumps(out))
     b.free()
     if use_dist:

@@ -54,19 +54,7 @@ def lib():
     return _lib
 
 
-def make_batch(seqs):
-    """GASAL host-batch wire format (reference host_batch.cpp:79-154): ASCII, each sequence padded
-    with 'N' to a multiple of 8 bytes; returns (bytes array, offsets, lens)."""
-    offs, lens, total = [], [], 0
-    for s in seqs:
-        offs.append(total)
-        lens.append(len(s))
-        total += (len(s) + 7) & ~7
-    buf = np.full(max(total, 8), ord("N"), dtype=np.uint8)
-    for s, o in zip(seqs, offs):
-        if len(s):
-            buf[o:o + len(s)] = np.frombuffer(s if isinstance(s, bytes) else s.encode(), dtype=np.uint8)
-    return buf[:total] if total else buf[:0], np.asarray(offs, np.uint32), np.asarray(lens, np.uint32)
+from agatha_amd.workload import make_batch  # noqa: E402  (wire-format helper lives in the product package)
 
 
 MODEL_SLICES, MODEL_STEPS, MODEL_EXACTBAND = 0, 1, 2

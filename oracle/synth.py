@@ -1,94 +1,3 @@
-"""Synthetic read-pair generators; shared by tests and bench.py.  Test/bench infrastructure."""
-import numpy as np
-
-_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
-
-
-def random_seq(rng, n):
-    return _ACGT[rng.integers(0, 4, size=int(n))]
-
-
-def mutate(rng, ref, sub, ins, dele):
-    """Independent per-base channel {substitution, insertion (uniform base), deletion}."""
-    n = ref.size
-    u = rng.random(n)
-    out = []
-    keep = u >= dele                       # deletion
-    is_sub = (u >= dele) & (u < dele + sub)
-    base = ref.copy()
-    if is_sub.any():
-        shift = rng.integers(1, 4, size=int(is_sub.sum()))
-        idx = np.searchsorted(_ACGT, base[is_sub])          # ACGT is sorted in ASCII
-        base[is_sub] = _ACGT[(idx + shift) % 4]
-    is_ins = rng.random(n) < ins
-    ins_base = random_seq(rng, n)
-    # interleave: for each position emit [ins_base if is_ins] + [base if keep]
-    cnt = is_ins.astype(np.int64) + keep.astype(np.int64)
-    pos = np.cumsum(cnt) - cnt
-    out = np.empty(int(cnt.sum()), dtype=np.uint8)
-    out[pos[is_ins]] = ins_base[is_ins]
-    out[(pos + is_ins)[keep]] = base[keep]
-    return out
-
-
-def make_pairs(seed, n, length_fn, sub=0.03, ins=0.03, dele=0.04, n_rate=0.0):
-    """Returns two lists of bytes objects: file-1 sequences (DP rows, 'query_batch') = the reference pieces,
-    file-2 sequences (DP columns, 'target_batch') = the mutated reads."""
-    rng = np.random.default_rng(seed)
-    qs, ts = [], []
-    for _ in range(n):
-        L = int(length_fn(rng))
-        ref = random_seq(rng, L)
-        read = mutate(rng, ref, sub, ins, dele)
-        if read.size == 0:
-            read = random_seq(rng, 1)
-        if n_rate > 0:
-            ref = ref.copy()
-            ref[rng.random(ref.size) < n_rate] = ord("N")
-        qs.append(ref.tobytes())
-        ts.append(read.tobytes())
-    return qs, ts
-
-
-def cfg_c1(n=10000, seed=0xA6A70001):
-    """10 k synthetic ONT pairs, ~10 kb, band 751 (BASELINE.json configs[1])."""
-    f = lambda rng: np.clip(np.rint(rng.normal(10000, 1000)), 8000, 12000)
-    return make_pairs(seed, n, f, 0.03, 0.03, 0.04)
-
-
-def cfg_c0(n=2000, seed=0xA6A70000):
-    """Bundled-dataset stand-in (the real dataset is absent from the reference tree)."""
-    f = lambda rng: np.clip(np.rint(rng.normal(3000, 1000)), 200, 8000)
-    return make_pairs(seed, n, f, 0.04, 0.03, 0.03)
-
-
-def cfg_c2(n=100000, seed=0xA6A70002):
-    f = lambda rng: rng.integers(15000, 20001)
-    return make_pairs(seed, n, f, 0.002, 0.004, 0.004)
-
-
-def cfg_c3(n=256, seed=0xA6A70003):
-    f = lambda rng: max(1000, np.rint(rng.normal(100000, 10000)))
-    return make_pairs(seed, n, f, 0.03, 0.03, 0.04)
-
-
-def cfg_c4(n=20000, seed=0xA6A70004, lo=1000, hi=100000):
-    """Mixed lengths, 30 % high-error / broken pairs that force z-drop."""
-    rng = np.random.default_rng(seed)
-    qs, ts = [], []
-    for _ in range(n):
-        L = int(np.exp(rng.uniform(np.log(lo), np.log(hi))))
-        ref = random_seq(rng, L)
-        if rng.random() < 0.7:
-            read = mutate(rng, ref, 0.03, 0.03, 0.04)
-        elif rng.random() < 0.5:
-            e = rng.uniform(0.25, 0.45) / 3
-            read = mutate(rng, ref, e, e, e)
-        else:
-            bp = int(rng.integers(0, L))
-            read = np.concatenate([mutate(rng, ref[:bp], 0.03, 0.03, 0.04), random_seq(rng, L - bp)])
-        if read.size == 0:
-            read = random_seq(rng, 1)
-        qs.append(ref.tobytes())
-        ts.append(read.tobytes())
-    return qs, ts
+"""Re-export of the product package's synthetic generators (kept so that tests can say `from oracle import synth`)."""
+from agatha_amd.workload import *  # noqa: F401,F403
+from agatha_amd.workload import _ACGT  # noqa: F401

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import agatha_amd  # noqa: E402
 from agatha_amd import shard  # noqa: E402
-from oracle import oracle as O, synth  # noqa: E402
+from agatha_amd import workload as synth  # noqa: E402
+from agatha_amd import workload as O  # noqa: E402  (make_batch only)
 
 eng = agatha_amd.Engine(0)
 out = {}

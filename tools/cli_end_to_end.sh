@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import sys, time
 sys.path.insert(0, ".")
-from oracle import synth
+from agatha_amd import workload as synth
 qs, ts = synth.cfg_c1(n=10000)
 for path, seqs in (("/tmp/ref.fasta", qs), ("/tmp/query.fasta", ts)):
     with open(path, "w") as f:
