@@ -97,6 +97,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    # RCCL / HIP print banners to fd 1 on some boxes (NCCL_DEBUG=VERSION): keep stdout clean for the ONE JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -222,7 +227,10 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(qb, tb, qo, to, ql, tl, dict(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND), W_BAND)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     b.free()
     if use_dist:
         dist.barrier()

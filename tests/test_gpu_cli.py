@@ -94,3 +94,19 @@ def test_cli_op_codes_with_c_flag(tmp_path):
     exp = np.stack(O.align_pairs([tr(s, o) for s, o in zip(qs, ops_q)], [tr(s, o) for s, o in zip(ts, ops_t)],
                                  O.make_params(w=100, z=200), wide=True), axis=1)
     assert (parse(r.stdout) == exp).all()
+
+
+def test_multi_gpu_front_end_single_rank(tmp_path):
+    """agatha_amd.multi_gpu under torch.distributed.run (1 rank here; the 8-GPU form is the same code path)."""
+    import sys
+    qs, ts = synth.cfg_c4(n=120, seed=3, lo=100, hi=5000)
+    f1, f2 = tmp_path / "ref.fasta", tmp_path / "query.fasta"
+    write_fasta(f1, qs)
+    write_fasta(f2, ts)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", "-m", "agatha_amd.multi_gpu", "-m", "1", "-x", "4", "-q", "6", "-r", "2", "-w", "100",
+           "-z", "100", "-a", "50", str(f1), str(f2)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exp = np.stack(O.align_pairs(qs, ts, O.make_params(m=1, x=4, q=6, r=2, s=3, z=100, w=100), wide=True, threads=4), axis=1)
+    assert (parse(r.stdout) == exp).all()
