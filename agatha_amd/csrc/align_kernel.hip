@@ -661,9 +661,9 @@ static hipError_t launch_align_t(const AlignLaunch& L, hipStream_t st)
 }
 
 struct Cfg { int G, S; hipError_t (*fn)(const AlignLaunch&, hipStream_t); };
-static const Cfg kCfgs[] = {
+static const Cfg kCfgs[] = {       // ascending G*S
     {16, 1, launch_align_t<16, 1>}, {16, 2, launch_align_t<16, 2>}, {16, 3, launch_align_t<16, 3>},
-    {32, 2, launch_align_t<32, 2>}, {32, 3, launch_align_t<32, 3>},
+    {32, 2, launch_align_t<32, 2>}, {64, 1, launch_align_t<64, 1>}, {32, 3, launch_align_t<32, 3>},
     {64, 2, launch_align_t<64, 2>}, {64, 3, launch_align_t<64, 3>}, {64, 4, launch_align_t<64, 4>},
     {64, 6, launch_align_t<64, 6>},
 };
@@ -700,14 +700,20 @@ hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint
 
 hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st)
 {
-    for (const Cfg& c : kCfgs) {
-        if (c.G * c.S >= window_blocks) {
-            if (G_out) *G_out = c.G;
-            if (S_out) *S_out = c.S;
-            return c.fn(L, st);
-        }
+    // Throughput choice: the smallest G*S that holds the window (most pairs per wave, fullest lanes).
+    const Cfg* pick = nullptr;
+    for (const Cfg& c : kCfgs)
+        if (c.G * c.S >= window_blocks) { pick = &c; break; }
+    if (!pick) return hipErrorInvalidValue;
+    // Latency choice for small batches: when even 64 lanes per pair leave SIMDs idle, spread each pair over a whole
+    // wave so that a lane sweeps fewer blocks per step (results do not depend on the shape).
+    if (L.n <= L.num_cus * 4) {
+        for (const Cfg& c : kCfgs)
+            if (c.G == 64 && c.G * c.S >= window_blocks && c.S < pick->S) { pick = &c; break; }
     }
-    return hipErrorInvalidValue;
+    if (G_out) *G_out = pick->G;
+    if (S_out) *S_out = pick->S;
+    return pick->fn(L, st);
 }
 
 hipError_t launch_pack(const uint8_t* unpacked, uint32_t nbytes, uint32_t* packed, hipStream_t st)

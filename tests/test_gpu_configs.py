@@ -43,7 +43,7 @@ def test_c2_hifi_band500_both_scorings(eng):
     for p in (dict(m=1, x=4, q=6, r=2, s=3, z=400, w=500),       # inside the reference's 16-bit domain
               dict(m=2, x=4, q=4, r=2, s=3, z=400, w=500)):      # scores reach 40 000: int32 ("wide") semantics
         batch, got = _run(eng, qs, ts, **p)
-        assert eng.last_config() == (32, 2)
+        assert eng.last_config() in ((32, 2), (64, 1))
         _check(batch, got, **p)
     assert got[0].max() > 32767
 
