@@ -319,8 +319,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
             for (int x = 0; x < 7; x++) A[x] = __builtin_elementwise_sub_sat(A[x], delta);
         }
 
-        // Which slots leave their column after this step is known now.  Right after a slot's block the packed words
-        // its NEXT step needs are requested into the registers that just became free, so a whole step hides the loads.
+        // Which slots leave their column after this step is known now (used by the prefetch after the slot loop).
         bool adv[S];
         bool any_adv = false;
 #pragma unroll
@@ -373,14 +372,17 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                 block8x8<true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, prof0 + s * (8 * 64),
                                   va, vnb, gapoe, ge, crel0, nrows, tu, tl, w - 8 * W, use_cmp);
             }
-            {   // prefetch for step i + 1 (the column's own words are dead from here on if it advances)
-                const int rn = adv[s] ? r + GS : r;
-                const int qn = i + 1 - rn;
-                uint32_t qv = 0u;
-                if (alive && qn >= 0 && qn < pql) qv = pq[qn];
-                qcur[s] = qv;
-                if (adv[s]) rword[s] = (rn < prl) ? pt[rn] : 0xEEEEEEEEu;
-            }
+        }
+        // Prefetch for step i + 1, issued once per step: every block of this step is done, so the registers are free,
+        // and the reduce / z-drop tail below hides the latency (nothing else waits on vmcnt in between).
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const int rn = adv[s] ? rcur[s] + GS : rcur[s];
+            const int qn = i + 1 - rn;
+            uint32_t qv = 0u;
+            if (alive && qn >= 0 && qn < pql) qv = pq[qn];
+            qcur[s] = qv;
+            if (adv[s]) rword[s] = (rn < prl) ? pt[rn] : 0xEEEEEEEEu;
         }
         // X[S] of the left neighbour lane becomes X[0]
 #pragma unroll
