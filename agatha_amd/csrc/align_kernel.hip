@@ -101,18 +101,20 @@ __device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge,
 // gasal_kernels.h:48-50.
 // MASKED: per-cell band test of boundary blocks and the row limit of the last row block, as EXEC masks
 //         built once per block (km: one lane mask per cell diagonal jl-il).
-template <bool MASKED, int K>
+template <bool MASKED, bool CMP, int K>
 __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, const int (&rh)[8], int (&e)[8],
                                          int (&oh)[8], int (&A)[15], uint32_t qword, uint32_t rword,
                                          const uint2* __restrict__ prof, int va, int vnb, int gapoe, int ge,
-                                         int crel0, int nrows, int tu, int tl, int t0, bool use_cmp)
+                                         int crel0, int nrows, int tu, int tl, int t0)
 {
     // all eight profile rows are requested up front: their LDS latency then hides behind the mask set-up and the
     // first rows instead of stalling every row (class of a query base = bits 3..1 of its code:
     // A(1)->0 C(3)->1 T(4)->2 G(7)->3 N(14)->7)
     uint2 pw[8];
+    if (!CMP) {
 #pragma unroll
-    for (int il = 0; il < 4; il++) pw[il] = prof[((qword >> (29 - 4 * il)) & 7u) * 64u];
+        for (int il = 0; il < 4; il++) pw[il] = prof[((qword >> (29 - 4 * il)) & 7u) * 64u];
+    }
     int cj[8];
 #pragma unroll
     for (int jl = 0; jl < 8; jl++) cj[jl] = crel0 + jl;
@@ -123,7 +125,7 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
         // wave-uniform predicates in SALU.  Anything else (clamped corners, bands narrower than a block) takes the
         // general per-lane compares.
         const bool up = (tu == t0) && (tl >= 7), lo = (tl == t0) && (tu >= 7), none = (tu >= 7) && (tl >= 7);
-        if (__all(up || lo || none)) {
+        if (__builtin_expect(__all(up || lo || none), 1)) {
             const unsigned long long mu = __builtin_amdgcn_ballot_w64(up), ml = __builtin_amdgcn_ballot_w64(lo);
 #pragma unroll
             for (int kk = 0; kk < 15; kk++)
@@ -137,13 +139,13 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
     }
 #pragma unroll
     for (int il = 0; il < 8; il++) {
-        if (il == 1) {                          // second half of the profile rows: requested three rows ahead of use
+        if (!CMP && il == 1) {                  // second half of the profile rows: requested three rows ahead of use
 #pragma unroll
             for (int i2 = 4; i2 < 8; i2++) pw[i2] = prof[((qword >> (29 - 4 * i2)) & 7u) * 64u];
         }
         if (!MASKED || il < nrows) {            // rows past the end of the query exist only in the last row block
             int t[8];
-            if (use_cmp) {
+            if (CMP) {
                 const uint32_t qb = (qword >> (28 - 4 * il)) & 15u;
 #pragma unroll
                 for (int jl = 0; jl < 8; jl++) {
@@ -208,7 +210,7 @@ __device__ __forceinline__ void build_profile(uint2* __restrict__ prof, uint32_t
     prof[7 * 64] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);                                          // query N: always -1
 }
 
-template <int G, int S>
+template <int G, int S, bool CMP>
 __global__ void __launch_bounds__(256, (S <= 3 ? 2 : 1))
 align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
 {
@@ -239,7 +241,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
     gptr_t pq = nullptr;
     gptr_t pt = nullptr;
     int i = 0, y = 0, ss = 0, se = 0, cb_prev = 0;
-    bool alive = false, exhausted = false, final_step = false, use_cmp_pair = false;
+    bool alive = false, exhausted = false, final_step = false;
     int best = 0, best_t = 0, best_q = 0;
 
     // ---- per-lane state ----
@@ -264,18 +266,21 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
     for (;;) {
         // ------------------------------------------------------------------ work queue
         const bool need = !alive && !exhausted;
-        if (__any(need)) {
+        if (__builtin_expect(__any(need), 0)) {
             int idx = 0;
-            if (need && k == 0) idx = (int)atomicAdd(La->queue, 1u);
+            if (need && k == 0) idx = (int)atomicAdd(La->queue + (CMP ? 1 : 0), 1u);
             idx = lane_read(idx, gbase);
             if (need) {
                 if (idx >= La->n) exhausted = true;
                 else {
                     pair = (int)La->order[idx];
+                    // two launches share the work: this instantiation only takes the pairs of its kind (the profile
+                    // kernel skips pairs with letters outside ACGTN, the compare kernel takes exactly those)
+                    const bool wants_cmp = La->force_cmp || (La->exotic[pair] != 0);
+                    if (wants_cmp == CMP) {
                     Q = (int)La->qlens[pair]; R = (int)La->tlens[pair];
                     pq = (gptr_t)(La->packed_q + (La->qoffs[pair] >> 3));
                     pt = (gptr_t)(La->packed_t + (La->toffs[pair] >> 3));
-                    use_cmp_pair = La->force_cmp || (La->exotic[pair] != 0);
                     pql = (Q + 7) >> 3; prl = (R + 7) >> 3;
                     total = prl + pql - 1; lim = Q + R - 1;
                     best = 0; best_t = 0; best_q = 0;
@@ -287,7 +292,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                         rcur[s] = k * S + s;
                         init_col(rcur[s], R, w, gapoe, ge, NEGK, h[s], f[s], corner[s]);
                         rword[s] = (rcur[s] < prl) ? pt[rcur[s]] : 0xEEEEEEEEu;
-                        build_profile(prof0 + s * (8 * 64), rword[s], P.match, P.mismatch);
+                        if (!CMP) build_profile(prof0 + s * (8 * 64), rword[s], P.match, P.mismatch);
                         const int q0 = 0 - rcur[s];                      // row block of step 0 (only column block 0 has one)
                         qcur[s] = (q0 >= 0 && q0 < pql) ? pq[q0] : 0u;
                     }
@@ -304,6 +309,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                         // with a window that does not hold the band (include/agatha_amd.h: AGATHA_AMD_BAD_RESULT)
                         if (k == 0) { La->score[pair] = INT_MIN; La->qend[pair] = -1; La->tend[pair] = -1; }
                         alive = false;
+                    }
                     }
                 }
             }
@@ -339,13 +345,13 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
             const int nrows = imin(8, Q - 8 * q);
             const bool boundary = (q == cs) || (q == ce);               // agatha_kernel.h:243
             if (active) {
-                if (y == 0 && r == prl - 1) {   // pass start: padded ref columns fall back to -inf (agatha_kernel.h:207-215)
+                if (__builtin_expect(y == 0 && r == prl - 1, 0)) {   // pass start: padded ref columns fall back to -inf (agatha_kernel.h:207-215)
 #pragma unroll
                     for (int m = 0; m < 8; m++) if (8 * r + m >= R) { h[s][m] = NEGK; f[s][m] = NEGK; }
                 }
                 const bool left_ok = (xr[s] == r - 1);
                 int rh[8];
-                if (__any(!left_ok && 8 * q <= w)) {
+                if (__builtin_expect(__any(!left_ok && 8 * q <= w), 0)) {
                     // a row block starts inside the first w rows: its left boundary holds real gap scores
 #pragma unroll
                     for (int il = 0; il < 8; il++) {
@@ -368,9 +374,8 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                 const int crel0 = 8 * r - cb;
                 // Edge blocks (band test) exist on every anti-diagonal, so a mask-free variant would rarely run for
                 // a whole wave; Ns are rare (padding of the last column block, occasional N in a read).
-                const bool use_cmp = __any(use_cmp_pair);     // some pair of this wave has letters outside ACGTN
-                block8x8<true, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, prof0 + s * (8 * 64),
-                                  va, vnb, gapoe, ge, crel0, nrows, tu, tl, w - 8 * W, use_cmp);
+                block8x8<true, CMP, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, prof0 + s * (8 * 64),
+                                       va, vnb, gapoe, ge, crel0, nrows, tu, tl, w - 8 * W);
             }
         }
         // Prefetch for step i + 1, issued once per step: every block of this step is done, so the registers are free,
@@ -408,7 +413,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
             for (int x = 1; x < 8; x++) hi8 = imax(hi8, vred[x]);
             calm = calm && lo8 != INT_MIN && (z < 0 || imax(best, hi8 >> K) - (lo8 >> K) <= z);
         }
-        if (__all(calm || !alive)) {
+        if (__builtin_expect(__all(calm || !alive), 1)) {
 #pragma unroll
             for (int x = 0; x < 8; x++) {
                 const int H = vred[x] >> K;
@@ -449,7 +454,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                     const int rn = rcur[s] + GS;
                     rcur[s] = rn;
                     init_col(rn, R, w, gapoe, ge, NEGK, h[s], f[s], corner[s]);
-                    build_profile(prof0 + s * (8 * 64), rword[s], P.match, P.mismatch);
+                    if (!CMP) build_profile(prof0 + s * (8 * 64), rword[s], P.match, P.mismatch);
                 }
             }
         }
@@ -465,7 +470,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                 if (ss > se) finished = alive;       // empty slice: stop without checking it (:189-191)
             }
         }
-        if (finished) {
+        if (__builtin_expect(finished, 0)) {
             if (k == 0) { La->score[pair] = best; La->qend[pair] = best_q; La->tend[pair] = best_t; }   // :359-363
             alive = false;
         }
@@ -658,7 +663,10 @@ static hipError_t launch_align_t(const AlignLaunch& L, hipStream_t st)
     if (L.max_blocks_override > 0) max_blocks = L.max_blocks_override;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((align_kernel<G, S>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
+    // profile kernel for the plain pairs, compare kernel for the (usually zero) pairs with other letters: the second
+    // launch only walks the queue when there is nothing for it
+    if (!L.force_cmp) hipLaunchKernelGGL((align_kernel<G, S, false>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
+    hipLaunchKernelGGL((align_kernel<G, S, true>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
     return hipGetLastError();
 }
 
@@ -680,7 +688,7 @@ int key_bits_for_window(int window_blocks)
     return -1;
 }
 
-__global__ void record_kernel(AlignLaunch L, AlignLaunch* rec) { *rec = L; *L.queue = 0u; }
+__global__ void record_kernel(AlignLaunch L, AlignLaunch* rec) { *rec = L; L.queue[0] = 0u; L.queue[1] = 0u; }
 
 hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st)
 {

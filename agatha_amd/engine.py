@@ -31,7 +31,7 @@ class Scores(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, _LIBNAME)
+    return os.environ.get("AGATHA_AMD_LIB") or os.path.join(_HERE, _LIBNAME)     # override: developer A/B builds only
 
 
 def build_library(force=False):
