@@ -17,12 +17,14 @@
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
+#include <stdio.h>
 
 #define NEG_INF2 (-16384)
 #define N_VALUE 14
 #define MAXG 64
 #define MAXS 8
 
+int32_t *agatha_dbg_dump = 0; int agatha_dbg_stride = 0;   /* debugging aid: H of every in-band cell */
 typedef struct { int32_t match, mismatch, gap_open, gap_extend, slice_width, z_threshold, band_width; } lm_params_t;
 
 static inline int imax(int a, int b) { return a > b ? a : b; }
@@ -147,6 +149,7 @@ int agatha_model_lanes(const char *qs, int Q, const char *rs, int R, const lm_pa
                             f[jl] = imax(tg, f[jl] - ge);
                             e = imax(tg, e - ge);
                             h[jl] = hn;
+                            if (agatha_dbg_dump) agatha_dbg_dump[(size_t)(8 * q + il) * agatha_dbg_stride + 8 * r + jl] = hn;
                             const int32_t key = (int32_t)((uint32_t)hn << K) + crel0 + jl;
                             ln->A[il + jl] = imax(ln->A[il + jl], key);
                         }
@@ -210,6 +213,277 @@ int agatha_model_lanes(const char *qs, int Q, const char *rs, int R, const lm_pa
     out3[0] = best; out3[1] = best_q; out3[2] = best_t;
     free(pq); free(L);
     return 0;
+}
+
+
+/*
+ * ---------------------------------------------------------------------------------------------------
+ * agatha_model_lanes16 -- emulation of the PACKED-INT16 kernel (agatha_amd/csrc/align16_kernel.hip).
+ *
+ * Same schedule as above; the arithmetic differs in three ways, all of which this model checks against the
+ * int32 model on the CPU before the kernel relies on them:
+ *   (1) all DP state is an int16 REPRESENTATION rep = value - base.  The base follows the running maximum
+ *       (rebased by L16_DELTA whenever an anti-diagonal maximum exceeds L16_REBASE), so sequence length does not
+ *       limit the domain.  Three disjoint zones: in-band values live in [L16_LO, ~L16_REBASE + 16*match]; the
+ *       reference's -infinity and what is derived from it in [L16_GLO, L16_LO); cells outside the band below L16_GLO.
+ *   (2) no per-cell band test.  Every cell of an active block is computed.  In a boundary block the band is cut by
+ *       subtracting L16_CUT instead of the gap-extension score on one cell diagonal: E leaving the band to the right
+ *       (cells with jl - il == tu) and F leaving it downwards (cells with il - jl == tl); state entering an
+ *       out-of-band cell from a neighbouring block is replaced by L16_OUT.  Out-of-band cells therefore only ever
+ *       hold values below L16_GLO, which lose every max against an in-band value, so in-band cells are unchanged;
+ *       an anti-diagonal whose maximum is below L16_GLO has no in-band cell and is reported empty, as the
+ *       reference does.
+ *       The rows of a lower boundary block whose last cell is outside the band hand on the same STALE values as
+ *       the reference (agatha_kernel.h:33 leaves its registers untouched).  Rows past the end of the query are
+ *       computed but kept out of the anti-diagonal maxima.
+ *   (3) the pair is abandoned (return 1 = "bail": the int32 kernel takes it) when an anti-diagonal maximum comes
+ *       within `spread` + L16_DELTA of L16_LO (an in-band cell could then drop out of its zone), or within `spread`
+ *       of the reference's -infinity in absolute terms, or is itself derived from -infinity (their exact values
+ *       would start to matter).
+ * stats[0] = min rep seen, stats[1] = max rep seen, stats[2] = largest garbage rep, stats[3] = smallest in-band rep.
+ * ---------------------------------------------------------------------------------------------------
+ */
+#define L16_LO     (-13000)    /* in-band values are >= L16_LO (enforced by the bail-out rule)                     */
+#define L16_NEG    (-13800)    /* the reference's -infinity; values derived from it stay in [L16_GLO, L16_LO)     */
+#define L16_GLO    (-14400)
+#define L16_OUT    (-30000)    /* state entering an out-of-band cell                                              */
+#define L16_CUT    17408       /* subtracted where E / F leave the band: lands below L16_GLO for any in-band value */
+#define L16_REBASE 2048
+#define L16_DELTA  2048
+
+int agatha_lanes16_spread(const lm_params_t *pr)
+{
+    const int gapoe = pr->gap_open + pr->gap_extend, ge = pr->gap_extend;
+    int per = 2 * ge; if (pr->mismatch > per) per = pr->mismatch; if (per < 1) per = 1;
+    return gapoe + per * (pr->band_width + 16) + 64;
+}
+
+/* 1 = these scores may run on the int16 kernel (a property of the launch, not of the pair) */
+int agatha_lanes16_eligible(const lm_params_t *pr)
+{
+    if (pr->band_width < 16) return 0;
+    if (pr->match < 0 || pr->match > 16 || pr->mismatch < 0 || pr->mismatch > 32) return 0;
+    if (pr->gap_open < 0 || pr->gap_open > 64 || pr->gap_extend < 0 || pr->gap_extend > 16) return 0;
+    if (agatha_lanes16_spread(pr) > 6000) return 0;
+    return 1;
+}
+
+static inline int32_t rep16(int64_t v) { return v < L16_LO ? L16_NEG : (int32_t)v; }
+
+static void init_col16(lane_t *ln, int s, int r, int R, int prl, int w, int gapoe, int ge, int base, const uint32_t *pt)
+{
+    for (int m = 0; m < 8; m++) {
+        int c = 8 * r + m;
+        if (c < R && c <= w) { ln->h[s][m] = rep16(-(gapoe + ge * c) - base); ln->f[s][m] = rep16(-(gapoe + ge * c) - gapoe - base); }
+        else { ln->h[s][m] = L16_NEG; ln->f[s][m] = L16_NEG; }
+    }
+    ln->corner[s] = (r == 0) ? rep16(0 - base) : ((8 * r - 1) <= w ? rep16(-(gapoe + ge * (8 * r - 1)) - base) : L16_NEG);
+    ln->rword[s] = (r < prl) ? pt[r] : 0xEEEEEEEEu;
+    ln->rcur[s] = r;
+}
+
+int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_params_t *pr,
+                         int G, int S, int32_t *out3, int32_t *stats)
+{
+    const int a = pr->match, b = pr->mismatch, gapoe = pr->gap_open + pr->gap_extend, ge = pr->gap_extend;
+    const int gapo = pr->gap_open;
+    const int sw = pr->slice_width, z = pr->z_threshold, w = pr->band_width;
+    const int W = (w + 7) / 8, GS = G * S;
+    if (G > MAXG || S > MAXS) return -1;
+    int K = 0; while ((1 << K) < 8 * (GS + 2)) K++;
+    const int32_t KMASK = (1 << K) - 1;
+    const int pql = (Q + 7) / 8, prl = (R + 7) / 8, total = prl + pql - 1, lim = Q + R - 1;
+    if (GS < imin(W + 1, imin(pql, prl))) return -1;
+    if (Q <= 0 || R <= 0) { out3[0] = out3[1] = out3[2] = 0; return 0; }
+    if (!agatha_lanes16_eligible(pr)) return 1;
+    const int spread = agatha_lanes16_spread(pr);
+    uint32_t *pq = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(pql + prl + 2)), *pt = pq + pql + 1;
+    pack_words(qs, Q, pq, pql); pack_words(rs, R, pt, prl);
+
+    lane_t *L = (lane_t *)calloc((size_t)G, sizeof(lane_t));
+    int base = 0;
+    for (int k = 0; k < G; k++) {
+        for (int s = 0; s < S; s++) init_col16(&L[k], s, k * S + s, R, prl, w, gapoe, ge, base, pt);
+        for (int s = 0; s <= S; s++) L[k].xr[s] = -2;
+        for (int x = 0; x < 15; x++) L[k].A[x] = INT_MIN;
+    }
+    int best = 0, best_t = 0, best_q = 0, stopped = 0, bail = 0;
+    int i = 0, y = 0, final = 0, cb_prev = 0;
+    int ss = 0, se = imin(imin(prl - 1, sw - 1), ((sw - 1) * 8 + 7 + w) / 2 / 8);
+    int32_t vmin = 0, vmax = 0, gmax = INT_MIN, rmin = INT_MAX;
+#define REB(v) ((v) >= L16_LO ? (v) - L16_DELTA : (v))      /* only in-band values follow the base */
+#define TRACK(v) do { if ((v) < vmin) vmin = (v); if ((v) > vmax) vmax = (v); } while (0)
+
+    for (;;) {
+        const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
+        for (int k = 0; k < G; k++)
+            for (int x = 0; x < 7; x++) L[k].A[x] = ssub_sat(L[k].A[x], cb - cb_prev);
+        for (int k = 0; k < G; k++) {
+            lane_t *ln = &L[k];
+            for (int s = S - 1; s >= 0; s--) {
+                const int r = ln->rcur[s], q = i - r;
+                const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
+                const int active = !final && r < prl && q >= cs && q <= ce && r >= ss && r <= se;
+                if (!active) { ln->xr[s + 1] = -2; continue; }
+                if (y == 0)
+                    for (int m = 0; m < 8; m++) if (8 * r + m >= R) { ln->h[s][m] = L16_NEG; ln->f[s][m] = L16_NEG; }
+                int32_t xh[8], xe[8], xe_in[8];
+                const int left_ok = (ln->xr[s] == r - 1);
+                for (int il = 0; il < 8; il++) {
+                    int row = 8 * q + il;
+                    if (left_ok) { xh[il] = ln->xh[s][il]; xe[il] = ln->xe[s][il]; }
+                    else if (row <= w) { xh[il] = rep16(-(gapoe + ge * row) - base); xe[il] = rep16(-(gapoe + ge * row) - gapoe - base); }
+                    else { xh[il] = L16_NEG; xe[il] = L16_NEG; }
+                }
+                memcpy(xe_in, xe, sizeof(xe_in));
+                const uint32_t qword = pq[q], rword = ln->rword[s];
+                const int nrows = imin(8, Q - 8 * q);
+                const int boundary = (q == cs || q == ce);
+                const int tu = boundary ? w + 8 * q - 8 * r : 1000;
+                const int tl = boundary ? w - 8 * q + 8 * r : 1000;
+                const int crel0 = 8 * r - cb;
+                int32_t *h = ln->h[s], *f = ln->f[s];
+                int32_t oh[8], oe[8];
+                int32_t cornerv = ln->corner[s];
+                /* entry cuts: state that enters an out-of-band cell of this block from a neighbouring block */
+                if (0 > tu || 0 > tl) cornerv = L16_OUT;
+                for (int m = 0; m < 8; m++) {
+                    const int out_c0 = (-m > tu) || (m > tl);           /* cell (m, 0) is outside the band */
+                    const int out_r0 = (m > tu) || (-m > tl);           /* cell (0, m) is outside the band */
+                    if (out_c0) { xe[m] = L16_OUT; if (m > 0) xh[m - 1] = L16_OUT; }    /* its E and its diagonal */
+                    if (out_r0) { f[m] = L16_OUT; if (m > 0) h[m - 1] = L16_OUT; }      /* its F and its diagonal */
+                }
+                for (int il = 0; il < 8; il++) {
+                    const int qb = (qword >> (28 - 4 * il)) & 15;       /* N beyond the query: packing pads with N */
+                    int32_t t[8];
+                    for (int jl = 0; jl < 8; jl++) {
+                        const int rb = (rword >> (28 - 4 * jl)) & 15;
+                        int sc = (qb == rb) ? a : -b;
+                        if (qb == N_VALUE || rb == N_VALUE) sc = -1;
+                        const int32_t d = jl == 0 ? (il == 0 ? cornerv : xh[il - 1]) : h[jl - 1];
+                        t[jl] = sc + d; TRACK(t[jl]);
+                    }
+                    int32_t e = xe[il];
+                    for (int jl = 0; jl < 8; jl++) {
+                        const int out = !((jl - il) <= tu && (il - jl) <= tl);
+                        const int32_t hn = imax(imax(t[jl], f[jl]), e);
+                        const int32_t u = t[jl] - gapo; TRACK(u);
+                        f[jl] = imax(u, f[jl]) - ((il - jl) == tl ? L16_CUT : ge); TRACK(f[jl]);
+                        e = imax(u, e) - ((jl - il) == tu ? L16_CUT : ge); TRACK(e);
+                        h[jl] = hn;
+                        if (out) { if (hn > gmax) gmax = hn; }
+                        else if (il < nrows) { if (hn < rmin) rmin = hn; }
+                        if (agatha_dbg_dump && !out && il < nrows) agatha_dbg_dump[(size_t)(8 * q + il) * agatha_dbg_stride + 8 * r + jl] = hn + base;
+                        if (il < nrows) {
+                            const int32_t key = (int32_t)((uint32_t)hn << K) + crel0 + jl;
+                            ln->A[il + jl] = imax(ln->A[il + jl], key);
+                        }
+                    }
+                    oh[il] = h[7]; oe[il] = e;
+                }
+                for (int il = 0; il < 8; il++)
+                    if (il - 7 > tl) { oh[il] = oh[imax(0, tl + 7)]; oe[il] = xe_in[il]; }
+                ln->corner[s] = xh[7];
+                memcpy(ln->xh[s + 1], oh, sizeof(oh)); memcpy(ln->xe[s + 1], oe, sizeof(oe));
+                ln->xr[s + 1] = r;
+            }
+        }
+        {
+            int32_t th[MAXG][8], te[MAXG][8]; int tr[MAXG];
+            for (int k = 0; k < G; k++) { memcpy(th[k], L[k].xh[S], sizeof(th[k])); memcpy(te[k], L[k].xe[S], sizeof(te[k])); tr[k] = L[k].xr[S]; }
+            for (int k = 0; k < G; k++) {
+                int src = (k + G - 1) % G;
+                memcpy(L[k].xh[0], th[src], sizeof(th[src])); memcpy(L[k].xe[0], te[src], sizeof(te[src])); L[k].xr[0] = tr[src];
+            }
+        }
+        int hi_rep = INT_MIN;
+        for (int x = 0; x < 8 && !stopped; x++) {
+            int32_t v = INT_MIN;
+            for (int k = 0; k < G; k++) v = imax(v, L[k].A[x]);
+            const int d = 8 * i + x;
+            if (v != INT_MIN && (v >> K) >= L16_LO) hi_rep = imax(hi_rep, v >> K);
+            if (!final && d >= lim) continue;
+            int H, c;
+            if (v == INT_MIN || (v >> K) < L16_GLO) { H = -32768; c = 0; }      /* empty, or only out-of-band cells */
+            else {
+                H = (v >> K) + base; c = (v & KMASK) + cb;
+                if ((v >> K) < L16_LO + spread + L16_DELTA || H < NEG_INF2 + spread) { bail = 1; break; }
+            }
+            if (H > best) { best = H; best_t = c; best_q = d - c; }
+            else if (c >= best_t && (d - c) >= best_q) {
+                int tlen = c - best_t, qlen = (d - c) - best_q;
+                int l = tlen > qlen ? tlen - qlen : qlen - tlen;
+                if (z >= 0 && best - H > z + l * ge) stopped = 1;
+            }
+        }
+        if (bail || stopped || final) break;
+        for (int k = 0; k < G; k++) {
+            for (int x = 0; x < 7; x++) L[k].A[x] = L[k].A[8 + x];
+            for (int x = 7; x < 15; x++) L[k].A[x] = INT_MIN;
+        }
+        cb_prev = cb;
+        /* rebase: keep the representation of the running maximum small */
+        if (hi_rep > L16_REBASE) {
+            base += L16_DELTA;
+            for (int k = 0; k < G; k++) {
+                lane_t *ln = &L[k];
+                for (int s = 0; s < S; s++) {
+                    for (int m = 0; m < 8; m++) { ln->h[s][m] = REB(ln->h[s][m]); ln->f[s][m] = REB(ln->f[s][m]); }
+                    ln->corner[s] = REB(ln->corner[s]);
+                }
+                for (int s = 0; s <= S; s++)
+                    for (int m = 0; m < 8; m++) { ln->xh[s][m] = REB(ln->xh[s][m]); ln->xe[s][m] = REB(ln->xe[s][m]); }
+                for (int x = 0; x < 7; x++) if (ln->A[x] != INT_MIN) ln->A[x] -= L16_DELTA << K;
+            }
+        }
+        for (int k = 0; k < G; k++)
+            for (int s = 0; s < S; s++) {
+                int r = L[k].rcur[s];
+                if (i + 1 - r > imin(pql - 1, r + W)) init_col16(&L[k], s, r + GS, R, prl, w, gapoe, ge, base, pt);
+            }
+        i++; y++;
+        if (y == sw) {
+            y = 0;
+            if (i >= total) final = 1;
+            else {
+                ss = imax(imax(0, i - pql + 1), (i * 8 + 8 - w) / 2 / 8);
+                se = imin(imin(prl - 1, i + sw - 1), ((i + sw - 1) * 8 + 7 + w) / 2 / 8);
+                if (ss > se) break;
+            }
+        }
+    }
+#undef TRACK
+#undef REB
+    out3[0] = best; out3[1] = best_q; out3[2] = best_t;
+    if (stats) { stats[0] = vmin; stats[1] = vmax; stats[2] = bail ? INT_MIN : gmax; stats[3] = bail ? INT_MAX : rmin; }
+    free(pq); free(L);
+    return bail;
+}
+
+/* kind[k]: 0 = aligned by the int16 model, 1 = ineligible / bailed out (out arrays hold the int32 model's answer) */
+void agatha_lanes16_batch(const uint8_t *qbatch, const uint8_t *tbatch, const uint32_t *qoff, const uint32_t *toff,
+                          const uint32_t *qlen, const uint32_t *tlen, int n, const lm_params_t *pr, int G, int S,
+                          int threads, int32_t *score, int32_t *qend, int32_t *tend, int32_t *kind, int32_t *stats4)
+{
+    (void)threads;
+    int32_t gmin = 0, gmax = 0, garb = INT_MIN, rmin = INT_MAX;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1) reduction(min:gmin) reduction(max:gmax) reduction(max:garb) reduction(min:rmin)
+#endif
+    for (int k = 0; k < n; k++) {
+        int32_t o[3] = {0, 0, 0}, st[4] = {0, 0, INT_MIN, INT_MAX};
+        int rc = agatha_model_lanes16((const char *)qbatch + qoff[k], (int)qlen[k], (const char *)tbatch + toff[k],
+                                      (int)tlen[k], pr, G, S, o, st);
+        if (rc == 1) rc = agatha_model_lanes((const char *)qbatch + qoff[k], (int)qlen[k], (const char *)tbatch + toff[k],
+                                             (int)tlen[k], pr, G, S, o) != 0 ? -1 : 1;
+        kind[k] = rc;
+        score[k] = o[0]; qend[k] = o[1]; tend[k] = o[2];
+        if (st[0] < gmin) gmin = st[0];
+        if (st[1] > gmax) gmax = st[1];
+        if (st[2] > garb) garb = st[2];
+        if (st[3] < rmin) rmin = st[3];
+    }
+    stats4[0] = gmin; stats4[1] = gmax; stats4[2] = garb; stats4[3] = rmin;
 }
 
 void agatha_lanes_batch(const uint8_t *qbatch, const uint8_t *tbatch, const uint32_t *qoff, const uint32_t *toff,

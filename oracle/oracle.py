@@ -48,6 +48,9 @@ def lib():
         _lib.agatha_lanes_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int,
                                                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _lib.agatha_lanes_batch.restype = None
+        _lib.agatha_lanes16_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int] + \
+                                                [C.c_void_p] * 5
+        _lib.agatha_lanes16_batch.restype = None
         _lib.ksw_style_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p,
                                                             C.c_void_p, C.POINTER(C.c_int)]
         _lib.ksw_style_batch.restype = None
@@ -86,6 +89,23 @@ def lanes_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, G, S, threads=1):
     if rc.value:
         raise ValueError("G*S too small for this band")
     return out[0], out[1], out[2]
+
+
+def lanes16_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, G, S, threads=1):
+    """CPU emulation of the packed-int16 kernel's arithmetic (no band masks, cut constants, bail-out to int32).
+    Returns (score, qend, tend, kind, stats): kind 0 = int16 path, 1 = fell back to the int32 model, -1 = window too
+    small; stats = (min rep, max rep, largest out-of-band rep, smallest in-band rep)."""
+    n = len(qlen)
+    qbuf = np.ascontiguousarray(qbuf, np.uint8)
+    tbuf = np.ascontiguousarray(tbuf, np.uint8)
+    arrs = [np.ascontiguousarray(a, np.uint32) for a in (qoff, toff, qlen, tlen)]
+    out = np.zeros((4, n), np.int32)
+    st = np.zeros(4, np.int32)
+    lib().agatha_lanes16_batch(qbuf.ctypes.data, tbuf.ctypes.data, *[a.ctypes.data for a in arrs], n,
+                               C.byref(params), int(G), int(S), int(threads),
+                               out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data,
+                               st.ctypes.data)
+    return out[0], out[1], out[2], out[3], st
 
 
 def ksw_style_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, threads=1):

@@ -103,3 +103,72 @@ def test_ksw_style_matches_reference_vectors_at_baseline_band():
         r = O.ksw_style_batch(g["qbatch"], g["tbatch"], g["qoff"], g["toff"], g["qlen"], g["tlen"],
                               O.make_params(**g["params"]), threads=4)
         assert all((x == y).all() for x, y in zip(r[:3], g["expect"])), g["name"]
+
+
+def _mixed_pairs(rng, n, lmax):
+    from agatha_amd.workload import random_seq, mutate
+    qs, ts = [], []
+    for _ in range(n):
+        L = int(rng.integers(1, lmax))
+        ref = random_seq(rng, L)
+        mode = int(rng.integers(0, 4))
+        if mode == 0:
+            rd = mutate(rng, ref, 0.03, 0.03, 0.04)
+        elif mode == 1:
+            rd = mutate(rng, ref, 0.15, 0.1, 0.1)
+        elif mode == 2:
+            rd = random_seq(rng, int(rng.integers(1, lmax)))
+        else:
+            bp = int(rng.integers(0, L))
+            rd = np.concatenate([mutate(rng, ref[:bp], 0.02, 0.02, 0.02), random_seq(rng, int(rng.integers(1, 600)))])
+        if rd.size == 0:
+            rd = random_seq(rng, 1)
+        if rng.random() < 0.2:
+            ref = ref.copy()
+            ref[rng.random(ref.size) < 0.05] = ord("N")
+        qs.append(ref.tobytes())
+        ts.append(rd.tobytes())
+    return qs, ts
+
+
+def test_lane_schedule_model_equals_oracle():
+    """The CPU emulation of the int32 kernel's lane/slot schedule is bit-identical to the slice-wise oracle."""
+    rng = np.random.default_rng(21)
+    for w, G, S in ((24, 16, 1), (100, 16, 1), (751, 32, 3)):
+        prm = O.make_params(2, 4, 4, 2, 3, 400, w)
+        qs, ts = _mixed_pairs(rng, 12, 1500)
+        qb, qo, ql = O.make_batch(qs)
+        tb, to, tl = O.make_batch(ts)
+        e = O.align_batch(qb, tb, qo, to, ql, tl, prm, wide=True, model=O.MODEL_SLICES, threads=4)
+        g = O.lanes_batch(qb, tb, qo, to, ql, tl, prm, G, S, threads=4)
+        for a, b in zip(e, g):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_int16_kernel_model_equals_oracle(seed):
+    """The packed-int16 kernel's arithmetic (oracle/agatha_lanes_model.c: rebased int16 representation, band cut by
+    constants instead of per-cell tests, bail-out to int32) gives the oracle's results, keeps every value inside
+    int16 and keeps its three value zones disjoint."""
+    rng = np.random.default_rng(seed)
+    fell_back = 0
+    for trial in range(10):
+        w = int(rng.choice([16, 17, 23, 24, 33, 47, 64, 100, 200, 751]))
+        z = int(rng.choice([-1, 0, 20, 100, 400, 2000]))
+        s = int(rng.choice([1, 2, 3, 5, 8]))
+        m, x, q, r = [(2, 4, 4, 2), (1, 4, 6, 2), (2, 3, 5, 1), (3, 5, 0, 1), (1, 1, 1, 1), (16, 32, 64, 16)][int(rng.integers(0, 6))]
+        prm = O.make_params(m, x, q, r, s, z, w)
+        qs, ts = _mixed_pairs(rng, 16, 2500)
+        qb, qo, ql = O.make_batch(qs)
+        tb, to, tl = O.make_batch(ts)
+        W = (w + 7) // 8
+        G, S = [c for c in ((16, 2), (16, 4), (16, 6), (32, 4), (32, 6), (64, 4)) if c[0] * c[1] >= W + 1][0]
+        e = O.align_batch(qb, tb, qo, to, ql, tl, prm, wide=True, model=O.MODEL_STEPS, threads=4)
+        sc, qe, te, kind, st = O.lanes16_batch(qb, tb, qo, to, ql, tl, prm, G, S, threads=4)
+        assert np.array_equal(e[0], sc) and np.array_equal(e[1], qe) and np.array_equal(e[2], te)
+        assert (kind >= 0).all()
+        fell_back += int((kind == 1).sum())
+        if (kind == 0).any():
+            assert st[0] >= -32768 and st[1] <= 32767          # no int16 wrap anywhere
+            assert st[2] < -14400 and st[3] >= -14400          # out-of-band cells below, in-band cells above L16_GLO
+    assert fell_back < 10 * 16 // 2

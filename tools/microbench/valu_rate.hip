@@ -49,6 +49,29 @@ __global__ void __launch_bounds__(256) k(int* out, int a, int b)
             if (OP == 30) { if (j & 1) asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); else asm volatile("v_sub_u32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); }
             if (OP == 31) { if (j & 4) asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); else asm volatile("v_sub_u32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); }
             if (OP == 32) { if (j == 7) asm volatile("s_and_b64 %0, %0, %1" : "+s"(m64) : "s"(m2)); else asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); }
+            if (OP == 34) asm volatile("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(v[j]) : "v"(b), "v"(a));
+            if (OP == 35) asm volatile("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(v[j]) : "v"(b), "v"(a));
+            if (OP == 36) asm volatile("v_add_u16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_2" : "+v"(v[j]) : "v"(b));
+            if (OP == 37) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(v[j]) : "v"(b));
+            if (OP == 38) asm volatile("v_pk_sub_i16 %0, %0, %1 clamp" : "+v"(v[j]) : "v"(b));
+            if (OP == 39) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(v[j]) : "v"(b));
+            if (OP == 40) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(v[j]) : "v"(b));
+            if (OP == 41) {   // one packed cell pair of the int16 kernel: 12 ops on a dependent chain, 8 chains in flight
+                int t, u, k1, k2;
+                asm volatile("v_add_u16_sdwa %0, %5, %6 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_1\n\t"
+                             "v_add_u16_sdwa %0, %5, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_2\n\t"
+                             "v_pk_max_u16 %1, %0, %7\n\t"
+                             "v_pk_max_u16 %1, %1, %4\n\t"
+                             "v_pk_sub_u16 %2, %0, %6\n\t"
+                             "v_pk_max_u16 %4, %2, %4\n\t"
+                             "v_pk_sub_u16 %4, %4, %6\n\t"
+                             "v_mad_u32_u16 %3, %1, %6, %7\n\t"
+                             "v_mad_u32_u16 %2, %1, %6, %7 op_sel:[1,0,0,0]\n\t"
+                             "v_max3_i32 %4, %4, %3, %2\n\t"
+                             "v_pk_max_u16 %0, %1, %0\n\t"
+                             "v_pk_sub_u16 %0, %0, %6"
+                             : "+v"(v[j]), "=&v"(t), "=&v"(u), "=&v"(k1), "+v"(v[(j + 1) & 7]) : "v"(v[(j + 2) & 7]), "v"(b), "v"(a));
+            }
             if (OP == 33) { if (j & 1) asm volatile("s_and_b64 %0, %0, %1" : "+s"(m64) : "s"(m2)); else asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[j]) : "v"(b)); }
         }
     }
@@ -80,9 +103,10 @@ double run(const char* name, int waves_per_simd)
 
 int main()
 {
-    for (int w : {1, 2, 3, 8}) {
-        run<0>("v_add_u32", w); run<1>("v_max_i32", w); run<30>("sub/max alt", w); run<31>("4sub+4max", w);
-        run<32>("7max+1salu", w); run<33>("4max+4salu", w);
+    for (int w : {1, 2}) {
+        run<1>("v_max_i32", w); run<4>("v_pk_max_i16", w); run<37>("v_pk_max_u16", w); run<40>("v_pk_sub_u16", w);
+        run<38>("pk_sub clamp", w); run<34>("mad_u32_u16", w); run<35>("mad_i32_i16", w); run<36>("add_u16 sdwa", w);
+        run<39>("v_alignbit", w); run<2>("v_max3_i32", w); run<41>("cell pair x12", w);
     }
     return 0;
 }
