@@ -1,0 +1,730 @@
+// align16_kernel.hip -- packed-int16 variant of the banded affine-gap extension kernel (gfx950, wave64).
+//
+// Same schedule as align_kernel.hip (one pair per G-lane group, band-stationary column state, one block-anti-diagonal
+// per step, eager z-drop), but every lane works on TWO adjacent column blocks at once: slots 2p (low half) and 2p+1
+// (high half) of a 32-bit register, v_pk_* arithmetic, i.e. two DP cells per VALU lane-op.  What makes that possible
+// and bit-exact (each point is emulated and checked against the oracle in oracle/agatha_lanes_model.c,
+// agatha_model_lanes16):
+//   * values are an unsigned 16-bit REPRESENTATION rep = value - base + 32768; `base` follows the running maximum of
+//     the pair, so sequence length does not limit the domain.  Three disjoint zones: in-band cells >= R_LO, the
+//     reference's -infinity and what derives from it in [R_GLO, R_LO), cells outside the band below R_GLO.
+//   * no per-cell band test (an EXEC mask cannot switch off half a register): every cell of an active block is computed,
+//     and the band is cut by subtracting R_CUT instead of the gap-extension score on ONE cell diagonal -- E leaving the
+//     band to the right in upper-edge blocks, F leaving it downwards in lower-edge blocks -- plus R_OUT on what
+//     enters an out-of-band cell from a neighbouring block.  Out-of-band cells then only hold values below R_GLO, lose
+//     every max against an in-band value, and an anti-diagonal whose maximum is below R_GLO is empty, as in the
+//     reference.  Lower-edge blocks hand on the reference's stale row values (agatha_kernel.h:33 skips, it does not
+//     reset).  Rows past the end of the query and inactive halves are kept out of the maxima by a zero multiplier in
+//     the key computation (v_mad_u32_u16).
+//   * a pair whose anti-diagonal maximum comes too close to the zone borders (an in-band cell could leave its zone, or
+//     the exact value of -infinity could start to matter) is abandoned and flagged for the int32 kernel.
+// The launcher only uses this kernel when the band's cut diagonal is t0 = w - 8*ceil(w/8) in {0, -1} (then every
+// boundary block is a regular upper or lower edge block) and the scores pass agatha16_scores_ok().
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+
+#include "kernels.h"
+#include "device_common.h"
+
+namespace agatha {
+
+namespace r16 {
+constexpr int BIAS = 32768;
+constexpr int LO = -13000 + BIAS;        // in-band values are >= LO (bail-out rule)
+constexpr int NEG = -13800 + BIAS;       // the reference's -infinity
+constexpr int GLO = -14400 + BIAS;       // below: out-of-band cells / nothing
+constexpr int OUT = -30000 + BIAS;       // state entering an out-of-band cell
+constexpr int CUT = 17408;               // subtracted where E / F leave the band
+constexpr int REBASE = 2048 + BIAS;      // rebase when an anti-diagonal maximum exceeds this
+constexpr int DELTA = 2048;
+}  // namespace r16
+
+__device__ __forceinline__ uint32_t pk2(uint32_t lo, uint32_t hi) { return (lo & 0xffffu) | (hi << 16); }
+__device__ __forceinline__ uint32_t dup2(uint32_t v) { return (v & 0xffffu) * 0x10001u; }
+__device__ __forceinline__ uint32_t hmask(bool lo, bool hi) { return (lo ? 0xffffu : 0u) | (hi ? 0xffff0000u : 0u); }
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }   // m ? a : b
+
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// ..._c: second operand is a wave-uniform constant (SGPR)
+__device__ __forceinline__ uint32_t pk_min_c(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_sub_c(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_add_c(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_sub_sat_c(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "s"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_shl_c(uint32_t a, uint32_t sh2) { uint32_t d; asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "s"(sh2), "v"(a)); return d; }
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_shl(uint32_t a, uint32_t sh2) { uint32_t d; asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "v"(sh2), "v"(a)); return d; }
+__device__ __forceinline__ int mad_lo(uint32_t h, uint32_t m, int c) { int d; asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(h), "v"(m), "v"(c)); return d; }
+__device__ __forceinline__ int mad_hi(uint32_t h, uint32_t m, int c) { int d; asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(h), "v"(m), "v"(c)); return d; }
+__device__ __forceinline__ int max3i(int a, int b, int c) { int d; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
+// representation of an in-band boundary value (value - base), or -infinity when it is out of the in-band zone
+__device__ __forceinline__ uint32_t rep16(int v_minus_base)
+{
+    const int r = v_minus_base + r16::BIAS;
+    return (uint32_t)(r < r16::LO ? r16::NEG : r);
+}
+
+// Initial state of column block r as 16-bit representations: H(-1, c), F(0, c) of its 8 columns and the corner
+// (agatha_kernel.h:133-148, 207-215), with R_OUT wherever the value would enter a cell of the column's first row block
+// that lies above the band (tu0: cells with jl - il > tu0 are outside).
+__device__ __forceinline__ void init_half(int r, int R, int w, int W, int gapoe, int ge, int base, uint32_t (&hv)[8], uint32_t (&fv)[8], uint32_t& cv)
+{
+    const int q0 = imax(0, r - W);
+    const int tu0 = w + 8 * q0 - 8 * r;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const int c = 8 * r + m;
+        const int k = -(gapoe + ge * c) - base;
+        const bool in = (c < R) && (c <= w);
+        uint32_t h = in ? rep16(k) : (uint32_t)r16::NEG;
+        uint32_t f = in ? rep16(k - gapoe) : (uint32_t)r16::NEG;
+        if (m > tu0) f = r16::OUT;                       // cell (0, m) of the first block is outside the band
+        if (m < 7 && m + 1 > tu0) h = r16::OUT;          // so is the cell this value is the diagonal of
+        hv[m] = h; fv[m] = f;
+    }
+    uint32_t c0 = (r == 0) ? rep16(0 - base) : ((8 * r - 1) <= w ? rep16(-(gapoe + ge * (8 * r - 1)) - base) : (uint32_t)r16::NEG);
+    if (0 > tu0) c0 = r16::OUT;
+    cv = c0;
+}
+
+// Score profile of one column block, four rows of 8 signed bytes (even columns in .x, odd in .y, column 0/1 in the
+// top byte): query-base classes 0..3 = A, C, T, G.
+__device__ __forceinline__ void build_profile5(uint2* __restrict__ prof, uint32_t rword, int a, int b)
+{
+    const uint32_t Re = (rword >> 4) & 0x0F0F0F0Fu, Ro = rword & 0x0F0F0F0Fu;
+    const uint32_t A4 = ((uint32_t)a & 0xFFu) * 0x01010101u, NB4 = ((uint32_t)(-b) & 0xFFu) * 0x01010101u;
+    const uint32_t BMe = NB4 | eq_bytes(Re, 0x0E0E0E0Eu), BMo = NB4 | eq_bytes(Ro, 0x0E0E0E0Eu);   // -b, or -1 where ref is N
+    const uint32_t codes[4] = {0x01010101u, 0x03030303u, 0x04040404u, 0x07070707u};              // A C T G
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t me = eq_bytes(Re, codes[c]), mo = eq_bytes(Ro, codes[c]);
+        prof[c * 64] = make_uint2((A4 & me) | (BMe & ~me), (A4 & mo) | (BMo & ~mo));
+    }
+}
+
+// packed query word -> class index per nibble: A(1)->0 C(3)->1 T(4)->2 G(7)->3.  Pairs with N in the query are not
+// given to this kernel (exotic_kernel); the N padding behind the end of a query only reaches rows that do not exist.
+__device__ __forceinline__ uint32_t class_word(uint32_t qword) { return (qword >> 1) & 0x33333333u; }
+
+// ---- the three hand-scheduled pieces of a block row.  They are single asm statements on purpose: the compiler cannot
+// see into inline asm and pads every short asm statement that feeds another with s_nop (it has to assume a partial-
+// register writer), which cost ~18% of the issue slots when each instruction was its own statement.  Inside a statement
+// the order below keeps the one real hazard of this code away: an SDWA write of half a register must be followed by at
+// least one other instruction before the register is read. ----
+
+// h[j] <- h[j-1] + score(row, column j) for both halves (h[-1] = d0: the value left of / above-left of the block), i.e.
+// the column state H of the row above is turned, in its own registers, into "diagonal + score" of this row.  Scores are
+// signed bytes: column j in byte 3 - j/2 of the even (.x) or odd (.y) word of the profile row (wl: low half, wh: high).
+// Order: all low halves from column 7 down to 0, then all high halves: every add reads its left neighbour before that
+// neighbour is overwritten, and a half-register write is never read by the next instruction.
+__device__ __forceinline__ void row_add_scores(uint32_t (&h)[8], uint32_t d0, uint2 wl, uint2 wh)
+{
+    asm("v_add_u16_sdwa %7, %6, sext(%10) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_0\n\t"
+        "v_add_u16_sdwa %6, %5, sext(%9) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_0\n\t"
+        "v_add_u16_sdwa %5, %4, sext(%10) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_1\n\t"
+        "v_add_u16_sdwa %4, %3, sext(%9) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_1\n\t"
+        "v_add_u16_sdwa %3, %2, sext(%10) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_2\n\t"
+        "v_add_u16_sdwa %2, %1, sext(%9) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_2\n\t"
+        "v_add_u16_sdwa %1, %0, sext(%10) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_3\n\t"
+        "v_add_u16_sdwa %0, %8, sext(%9) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_3\n\t"
+        "v_add_u16_sdwa %7, %6, sext(%12) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_0\n\t"
+        "v_add_u16_sdwa %6, %5, sext(%11) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_0\n\t"
+        "v_add_u16_sdwa %5, %4, sext(%12) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1\n\t"
+        "v_add_u16_sdwa %4, %3, sext(%11) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1\n\t"
+        "v_add_u16_sdwa %3, %2, sext(%12) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_2\n\t"
+        "v_add_u16_sdwa %2, %1, sext(%11) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_2\n\t"
+        "v_add_u16_sdwa %1, %0, sext(%12) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3\n\t"
+        "v_add_u16_sdwa %0, %8, sext(%11) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3"
+        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7])
+        : "v"(d0), "v"(wl.x), "v"(wl.y), "v"(wh.x), "v"(wh.y));
+}
+
+// four cells of a row: t comes in as diagonal + score and leaves as the new H; F of the four columns and the row's E are
+// advanced (gap-extension operands gf*, ge* per cell: the gap-extension score, or R_CUT on a cut diagonal)
+__device__ __forceinline__ void row_cells4(uint32_t& t0, uint32_t& t1, uint32_t& t2, uint32_t& t3, uint32_t& f0, uint32_t& f1,
+                                           uint32_t& f2, uint32_t& f3, uint32_t& ev, uint32_t gapo, uint32_t gf0, uint32_t gf1,
+                                           uint32_t gf2, uint32_t gf3, uint32_t ge0, uint32_t ge1, uint32_t ge2_, uint32_t ge3)
+{
+    uint32_t x, u;
+#define AGATHA16_CELL(T, F, GF, GE) \
+        "v_pk_max_u16 %[x], " T ", " F "\n\t" \
+        "v_pk_sub_u16 %[u], " T ", %[gapo]\n\t" \
+        "v_pk_max_u16 " T ", %[x], %[ev]\n\t" \
+        "v_pk_max_u16 " F ", %[u], " F "\n\t" \
+        "v_pk_max_u16 %[ev], %[u], %[ev]\n\t" \
+        "v_pk_sub_u16 " F ", " F ", " GF "\n\t" \
+        "v_pk_sub_u16 %[ev], %[ev], " GE "\n\t"
+    asm(AGATHA16_CELL("%[t0]", "%[f0]", "%[gf0]", "%[ge0]")
+        AGATHA16_CELL("%[t1]", "%[f1]", "%[gf1]", "%[ge1]")
+        AGATHA16_CELL("%[t2]", "%[f2]", "%[gf2]", "%[ge2]")
+        AGATHA16_CELL("%[t3]", "%[f3]", "%[gf3]", "%[ge3]")
+        : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [f0] "+v"(f0), [f1] "+v"(f1), [f2] "+v"(f2), [f3] "+v"(f3),
+          [ev] "+v"(ev), [x] "=&v"(x), [u] "=&v"(u)
+        : [gapo] "s"(gapo), [gf0] "v"(gf0), [gf1] "v"(gf1), [gf2] "v"(gf2), [gf3] "v"(gf3), [ge0] "v"(ge0), [ge1] "v"(ge1),
+          [ge2] "v"(ge2_), [ge3] "v"(ge3));
+#undef AGATHA16_CELL
+}
+
+// packed maxima of four cells.  A[d] collects, for cell anti-diagonal d = il + jl of the block pair, the maximum of
+// H * kmul + (relative column of the block - il): the "+ d" that turns it into H * 2^K + relative column of the cell
+// is the same for every candidate of an accumulator and is added when the accumulators are read.  kmul = 2^K, or 0
+// where the row does not exist.
+__device__ __forceinline__ void row_keys4(int& a0, int& a1, int& a2, int& a3, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
+                                          uint32_t kmul, int rowc_lo, int rowc_hi)
+{
+    int x, y;
+#define AGATHA16_KEY(A, H) \
+        "v_mad_u32_u16 %[x], " H ", %[km], %[rl]\n\t" \
+        "v_mad_u32_u16 %[y], " H ", %[km], %[rh] op_sel:[1,1,0,0]\n\t" \
+        "v_max3_i32 " A ", " A ", %[x], %[y]\n\t"
+    asm(AGATHA16_KEY("%[a0]", "%[h0]")
+        AGATHA16_KEY("%[a1]", "%[h1]")
+        AGATHA16_KEY("%[a2]", "%[h2]")
+        AGATHA16_KEY("%[a3]", "%[h3]")
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [x] "=&v"(x), [y] "=&v"(y)
+        : [h0] "v"(h0), [h1] "v"(h1), [h2] "v"(h2), [h3] "v"(h3), [km] "v"(kmul), [rl] "v"(rowc_lo), [rh] "v"(rowc_hi));
+#undef AGATHA16_KEY
+}
+
+template <int K>
+__device__ __forceinline__ void block_pair16(uint32_t (&h)[8], uint32_t (&f)[8], uint32_t corner, const uint32_t (&rh)[8],
+                                             uint32_t (&e)[8], uint32_t (&oh)[8], int (&A)[15], uint32_t qc_lo, uint32_t qc_hi,
+                                             const uint2* __restrict__ pl, const uint2* __restrict__ ph, uint32_t gapo2,
+                                             uint32_t ge2, uint32_t gee0, uint32_t geem1, uint32_t gef0, uint32_t gef1, uint32_t NR,
+                                             int crel_lo, int crel_hi, uint32_t one2, uint32_t k2)
+{
+    // profile rows are requested while the previous row's cells are being computed
+    uint2 wl = pl[((qc_lo >> 28) & 3u) * 64u], wh = ph[((qc_hi >> 28) & 3u) * 64u];
+#pragma unroll
+    for (int il = 0; il < 8; il++) {
+        // key multiplier of this row: 2^K where the row exists, 0 where it does not
+        const uint32_t kmul = pk_shl_c(pk_min_c(pk_sub_sat_c(NR, dup2((uint32_t)il)), one2), k2);
+        row_add_scores(h, il == 0 ? corner : rh[il > 0 ? il - 1 : 0], wl, wh);
+        if (il < 7) {
+            wl = pl[((qc_lo >> (24 - 4 * il)) & 3u) * 64u];
+            wh = ph[((qc_hi >> (24 - 4 * il)) & 3u) * 64u];
+        }
+        uint32_t ev = e[il];
+        // per-cell gap-extension operands: cell diagonal jl - il == 0 / -1 (E) and 0 / +1 (F) may be cut
+#define GE_E(jl) ((jl) - il == 0 ? gee0 : (jl) - il == -1 ? geem1 : ge2)
+#define GE_F(jl) ((jl) - il == 0 ? gef0 : (jl) - il == 1 ? gef1 : ge2)
+        row_cells4(h[0], h[1], h[2], h[3], f[0], f[1], f[2], f[3], ev, gapo2, GE_F(0), GE_F(1), GE_F(2), GE_F(3), GE_E(0), GE_E(1), GE_E(2), GE_E(3));
+        row_cells4(h[4], h[5], h[6], h[7], f[4], f[5], f[6], f[7], ev, gapo2, GE_F(4), GE_F(5), GE_F(6), GE_F(7), GE_E(4), GE_E(5), GE_E(6), GE_E(7));
+#undef GE_E
+#undef GE_F
+        row_keys4(A[il], A[il + 1], A[il + 2], A[il + 3], h[0], h[1], h[2], h[3], kmul, crel_lo - il, crel_hi - il);
+        row_keys4(A[il + 4], A[il + 5], A[il + 6], A[il + 7], h[4], h[5], h[6], h[7], kmul, crel_lo - il, crel_hi - il);
+        oh[il] = h[7]; e[il] = ev;
+    }
+}
+
+// ---- packed per-half control arithmetic: column indices, row-block indices and tags are 16-bit (sequences shorter
+// than 262 136 bases; longer pairs go to the int32 kernel), masks are 0xFFFF / 0 per half ----
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_sar15(uint32_t a, uint32_t f15) { uint32_t d; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(d) : "s"(f15), "v"(a)); return d; }
+// a < b as signed 16-bit numbers whose difference fits 16 bits
+__device__ __forceinline__ uint32_t lt_mask(uint32_t a, uint32_t b, uint32_t f15) { return pk_sar15(pk_sub(a, b), f15); }
+// a == b
+__device__ __forceinline__ uint32_t eq_mask(uint32_t a, uint32_t b, uint32_t one2) { return pk_sub_c(pk_min_c(a ^ b, one2), one2); }
+
+template <int G, int P>
+__global__ void __launch_bounds__(256, 2)
+align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
+{
+    constexpr int S = 2 * P, GS = G * S;
+    constexpr int K = KeyBits<GS>::value;
+    constexpr int KMASK = (1 << K) - 1;
+
+    __shared__ uint2 s_prof[4 * S * 4 * 64];      // [wave][slot][class][lane] score profiles
+    // E(row, column right of the block) of every slot, one 16-bit value per row: what slot s wrote in step i is the E
+    // input of slot s + 1 in step i + 1.  Region S double-buffers slot S-1 (read by the NEXT lane's slot 0 one step
+    // later, after this lane has already written the new values): steps with odd i write region S, even i region S-1.
+    // Row 8 of a region holds the column block the eight values belong to (0xFFFE = none).
+    __shared__ uint16_t s_xe[4 * (S + 1) * 9 * 64];
+    const int lane = threadIdx.x & 63;
+    uint2* const prof0 = s_prof + (threadIdx.x >> 6) * (S * 4 * 64) + lane;
+    uint16_t* const xe_wave = s_xe + (threadIdx.x >> 6) * ((S + 1) * 9 * 64);
+    const int k = lane & (G - 1);
+    const int gbase = lane & ~(G - 1);
+    const int left_lane = gbase | ((k + G - 1) & (G - 1));
+
+    const int gapo = Pm.gap_open, ge = Pm.gap_extend, gapoe = gapo + ge;
+    const int sw = Pm.slice_width, z = Pm.z_threshold, w = Pm.band_width;
+    const int W = (w + 7) >> 3;
+    const int t0 = w - 8 * W;                      // 0 or -1 here (launcher); the cut diagonal of edge blocks
+    int spread;                                    // how far below an anti-diagonal maximum an in-band cell can be
+    {
+        int per = 2 * ge; if (Pm.mismatch > per) per = Pm.mismatch; if (per < 1) per = 1;
+        spread = gapoe + per * (w + 16) + 64;
+    }
+    const int bail_rep = r16::LO + spread + r16::DELTA;
+    const uint32_t GAPO2 = dup2((uint32_t)gapo), GE2 = dup2((uint32_t)ge), CUT2 = dup2(r16::CUT);
+    const uint32_t NEG2 = dup2(r16::NEG), OUT2 = dup2(r16::OUT), ONE2 = 0x00010001u, K2 = dup2(K), F15 = 0x000F000Fu;
+    const uint32_t W2 = dup2((uint32_t)W), NOTAG = 0xFFFEFFFEu;
+    // initial state of a column block beyond the first band width (init_half with r > W): constants per column
+    const uint32_t HINIT = (t0 < 0) ? OUT2 : OUT2, H7INIT = NEG2;     // h[m], m < 7: the cell it is the diagonal of, (0, m+1), is outside for t0 <= 0
+    const uint32_t F0INIT = (0 > t0) ? OUT2 : NEG2, FINIT = OUT2, CINIT = (0 > t0) ? OUT2 : NEG2;
+
+    // ---- per-pair state (uniform inside a group) ----
+    int Q = 0, R = 0, pair = 0, base = 0;
+    typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
+    uint32_t pq = 0, pt = 0;                        // word offsets of the pair's sequences in the packed batches
+    int i = 0, y = 0, ss = 0, se = 0;
+    bool alive = false, exhausted = false, final_step = false;
+    int best = 0, best_t = 0, best_q = 0;
+
+    // ---- per-lane state, one register per slot PAIR (low half = slot 2p, high half = slot 2p + 1) ----
+    uint32_t RC[P];                                 // column block of each slot
+    uint32_t H[P][8], F[P][8], CORNER[P];
+    uint32_t XH[P][8];                              // row hand-off of H (registers); E goes through s_xe
+    uint32_t qcls[S];
+    int A[15];
+
+#pragma unroll
+    for (int s = 0; s < S; s++) qcls[s] = 0;
+#pragma unroll
+    for (int p = 0; p < P; p++) { CORNER[p] = 0; RC[p] = 0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) { H[p][m] = 0; F[p][m] = 0; XH[p][m] = 0; } }
+#pragma unroll
+    for (int x = 0; x < 15; x++) A[x] = 0;
+
+    for (;;) {
+        // ------------------------------------------------------------------ work queue
+        const bool need = !alive && !exhausted;
+        if (__builtin_expect(__any(need), 0)) {
+            int idx = 0;
+            if (need && k == 0) idx = (int)atomicAdd(La->queue + 0, 1u);
+            idx = lane_read(idx, gbase);
+            if (need) {
+                if (idx >= La->n) exhausted = true;
+                else {
+                    pair = (int)La->order[idx];
+                    if (La->exotic[pair] == 0) {           // kind 0: plain letters, not yet handed to the int32 kernel
+                        Q = (int)La->qlens[pair]; R = (int)La->tlens[pair];
+                        pq = La->qoffs[pair] >> 3;
+                        pt = La->toffs[pair] >> 3;
+                        const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
+                        best = 0; best_t = 0; best_q = 0; base = 0;
+                        // The pair starts with a dry step i = -1: no block is active in it, and the code that puts the
+                        // initial column state back into slots that have not started yet (below, after each block pair)
+                        // thereby initialises every slot.  Assigning that state here instead would make the register
+                        // allocator copy ~100 registers on every trip round the main loop.
+                        i = -1; y = -1; final_step = false;
+                        ss = 0;
+                        se = imin(imin(prl - 1, sw - 1), (((sw - 1) * 8 + 7 + w) / 2) / 8);
+                        int kk = k;                 // laundered: nothing below is worth hoisting out of the main loop
+                        asm volatile("" : "+v"(kk));
+#pragma unroll
+                        for (int p = 0; p < P; p++) {
+                            const int ra = kk * S + 2 * p, rb = ra + 1;
+                            RC[p] = pk2((uint32_t)ra, (uint32_t)rb);
+#pragma unroll
+                            for (int hf = 0; hf < 2; hf++) {
+                                const int r = ra + hf, s = 2 * p + hf;
+                                const uint32_t rw0 = (r < prl) ? ((gptr_t)La->packed_t)[pt + (uint32_t)r] : 0xEEEEEEEEu;
+                                build_profile5(prof0 + s * (4 * 64), rw0, Pm.match, Pm.mismatch);
+                            }
+                        }
+#pragma unroll
+                        for (int x = 0; x < 15; x++) A[x] = 0;
+                        alive = true;
+                        if (Q <= 0 || R <= 0) {
+                            if (k == 0) { La->score[pair] = 0; La->qend[pair] = 0; La->tend[pair] = 0; }
+                            alive = false;
+                        } else if (imin(W + 1, imin(pql, prl)) > GS) {
+                            if (k == 0) { La->score[pair] = INT_MIN; La->qend[pair] = -1; La->tend[pair] = -1; }
+                            alive = false;
+                        } else if (pql + GS >= 32760 || prl + GS >= 32760) {      // indices are 16 bits wide here
+                            if (k == 0) La->exotic[pair] = 2;
+                            alive = false;
+                        }
+                    }
+                }
+            }
+        }
+        if (!__any(alive)) {
+            if (__all(exhausted)) break;           // else every group drew a pair of another kind: draw again
+        } else {
+
+        // ------------------------------------------------------------------ one step
+        const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
+        const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
+        {
+            const int cb_prev = 8 * imax(0, imax(i - pql, (i - W) >> 1) - 1);       // the same formula for step i - 1
+            const int delta = cb - cb_prev;       // 0 or 8
+#pragma unroll
+            for (int x = 0; x < 7; x++) A[x] -= delta;
+        }
+        const int total = prl + pql - 1, lim = Q + R - 1;
+        const uint32_t I2 = dup2((uint32_t)i), PQL1 = dup2((uint32_t)(pql - 1));
+        const uint32_t SS2 = dup2((uint32_t)ss), SE2 = dup2((uint32_t)imin(se, prl - 1));
+        const uint32_t RUNm = (alive && !final_step) ? 0xFFFFFFFFu : 0u;
+        const uint32_t NRLAST = dup2((uint32_t)(Q - 8 * (pql - 1)));
+        bool bail = false;
+
+#pragma unroll
+        for (int p = P - 1; p >= 0; p--) {
+            __builtin_amdgcn_sched_barrier(0);      // keep the three block pairs apart: interleaving them costs registers
+            const uint32_t rc = RC[p];
+            const uint32_t q2 = pk_sub(I2, rc);                                    // row block of each half (signed)
+            const uint32_t cs2 = pk_sub_sat(rc, W2), ce2 = pk_min(pk_add(rc, W2), PQL1);
+            // active: cs <= q <= ce, ss <= r <= min(se, prl - 1), pair running
+            const uint32_t ACTm = ~(lt_mask(q2, cs2, F15) | lt_mask(ce2, q2, F15) | lt_mask(rc, SS2, F15) | lt_mask(SE2, rc, F15)) & RUNm;
+            {
+                const int ra = (int)(rc & 0xffffu), rb = (int)(rc >> 16);
+                // regular edge blocks: q == r - W (upper, cut on cell diagonal t0), q == r + W (lower, cut on -t0);
+                // every other block is uncut when t0 is 0 or -1
+                const uint32_t UPm = eq_mask(pk_add(q2, W2), rc, ONE2) & ACTm, LOm = eq_mask(q2, pk_add(rc, W2), ONE2) & ACTm;
+
+                if (__builtin_expect(y == 0 && ACTm != 0u && (ra == prl - 1 || rb == prl - 1), 0)) {
+                    // pass start: padded ref columns fall back to -infinity (agatha_kernel.h:207-215); where the value
+                    // would enter an out-of-band cell of an upper edge block it is R_OUT as in init_half
+                    const bool acta = (ACTm & 1u) != 0u, actb = (ACTm >> 31) != 0u;
+                    const int tua = (UPm & 1u) ? t0 : 1000, tub = (UPm >> 31) ? t0 : 1000;
+#pragma unroll
+                    for (int m = 0; m < 8; m++) {
+                        const bool pa = acta && ra == prl - 1 && 8 * ra + m >= R, pb = actb && rb == prl - 1 && 8 * rb + m >= R;
+                        const uint32_t fva = (m > tua) ? r16::OUT : r16::NEG, fvb = (m > tub) ? r16::OUT : r16::NEG;
+                        const uint32_t hva = (m < 7 && m + 1 > tua) ? r16::OUT : r16::NEG, hvb = (m < 7 && m + 1 > tub) ? r16::OUT : r16::NEG;
+                        const uint32_t pm = hmask(pa, pb);
+                        F[p][m] = bfi(pm, pk2(fva, fvb), F[p][m]);
+                        H[p][m] = bfi(pm, pk2(hva, hvb), H[p][m]);
+                    }
+                }
+
+                // ---- row inputs: the left neighbour's output of the previous step, or the boundary ----
+                uint32_t rh[8], e[8];
+                // E inputs: low half from the slot to the left (the previous lane's last slot for p == 0), high half from
+                // this pair's own low slot, both as written one step ago
+                uint32_t xin[8], tagin;
+                {
+                    const uint16_t* src_lo = (p > 0) ? xe_wave + lane + (2 * p - 1) * (9 * 64)
+                                                     : xe_wave + left_lane + (((i - 1) & 1) ? S : S - 1) * (9 * 64);
+                    const uint16_t* src_hi = xe_wave + lane + (2 * p) * (9 * 64);
+#pragma unroll
+                    for (int il = 0; il < 8; il++) xin[il] = (uint32_t)src_lo[il * 64] | ((uint32_t)src_hi[il * 64] << 16);
+                    tagin = (uint32_t)src_lo[8 * 64] | ((uint32_t)src_hi[8 * 64] << 16);
+                }
+                const uint32_t okm = eq_mask(tagin, pk_sub(rc, ONE2), ONE2);
+                // a row block inside the first w rows whose left input is missing starts from real gap scores
+                const uint32_t FRMm = ACTm & ~okm & lt_mask(q2, dup2((uint32_t)(w / 8 + 1)), F15);
+                if (__builtin_expect(__any(FRMm != 0u), 0)) {
+                    // (agatha_kernel.h:126-131); general per-lane form of the entry rules
+                    const bool oka = (okm & 1u) != 0u, okb = (okm >> 31) != 0u;
+                    const int qa = i - ra, qb = i - rb;
+                    const int tua = (UPm & 1u) ? t0 : 1000, tub = (UPm >> 31) ? t0 : 1000;
+                    const int tla = (LOm & 1u) ? t0 : 1000, tlb = (LOm >> 31) ? t0 : 1000;
+#pragma unroll
+                    for (int il = 0; il < 8; il++) {
+                        const int rowa = 8 * qa + il, rowb = 8 * qb + il;
+                        const int ka = -(gapoe + ge * rowa) - base, kb = -(gapoe + ge * rowb) - base;
+                        uint32_t iha = (rowa <= w) ? rep16(ka) : (uint32_t)r16::NEG, iea = (rowa <= w) ? rep16(ka - gapoe) : (uint32_t)r16::NEG;
+                        uint32_t ihb = (rowb <= w) ? rep16(kb) : (uint32_t)r16::NEG, ieb = (rowb <= w) ? rep16(kb - gapoe) : (uint32_t)r16::NEG;
+                        uint32_t vha = oka ? (XH[p][il] & 0xffffu) : iha, vea = oka ? (xin[il] & 0xffffu) : iea;
+                        uint32_t vhb = okb ? (XH[p][il] >> 16) : ihb, veb = okb ? (xin[il] >> 16) : ieb;
+                        // cell (il, 0) outside the band: its E is R_OUT; cell (il + 1, 0) outside: its diagonal (this H) is
+                        if ((-il > tua) || (il > tla)) vea = r16::OUT;
+                        if ((-il > tub) || (il > tlb)) veb = r16::OUT;
+                        if (il < 7 && ((-(il + 1) > tua) || (il + 1 > tla))) vha = r16::OUT;
+                        if (il < 7 && ((-(il + 1) > tub) || (il + 1 > tlb))) vhb = r16::OUT;
+                        rh[il] = pk2(vha, vhb); e[il] = pk2(vea, veb);
+                    }
+                } else {
+                    // lower edge blocks: every cell of column 0 below the cut is outside the band, so the missing left
+                    // input is R_OUT there (for t0 = 0 cell (0, 0) is inside); everywhere else it is -infinity
+                    const uint32_t dflt = bfi(LOm, OUT2, NEG2);
+                    const uint32_t dflt_e0 = (t0 == 0) ? NEG2 : dflt;
+#pragma unroll
+                    for (int il = 0; il < 8; il++) {
+                        rh[il] = bfi(okm, XH[p][il], il < 7 ? dflt : NEG2);
+                        e[il] = bfi(okm, xin[il], il == 0 ? dflt_e0 : dflt);
+                    }
+                    // upper edge blocks: cell (0, 0) is outside when t0 = -1
+                    if (t0 < 0) e[0] = bfi(UPm, OUT2, e[0]);
+                }
+                uint32_t corner_in = CORNER[p];
+                if (t0 < 0) {
+                    corner_in = bfi(UPm | LOm, OUT2, corner_in);
+                    F[p][0] = bfi(LOm, OUT2, F[p][0]);       // lower edge blocks: cell (0, 0) is outside when t0 = -1
+                }
+
+                // ---- what E and F lose per step on the cut diagonals ----
+                const uint32_t gcu = bfi(UPm, CUT2, GE2), gcl = bfi(LOm, CUT2, GE2);
+                const uint32_t gee0 = (t0 == 0) ? gcu : GE2, geem1 = (t0 == -1) ? gcu : GE2;
+                const uint32_t gef0 = (t0 == 0) ? gcl : GE2, gef1 = (t0 == -1) ? gcl : GE2;
+                // rows that exist: 8, fewer in the last row block, 0 for an inactive half
+                const uint32_t NR = bfi(eq_mask(q2, PQL1, ONE2), NRLAST, 0x00080008u) & ACTm;
+
+                block_pair16<K>(H[p], F[p], corner_in, rh, e, XH[p], A, qcls[2 * p], qcls[2 * p + 1], prof0 + (2 * p) * (4 * 64),
+                                prof0 + (2 * p + 1) * (4 * 64), GAPO2, GE2, gee0, geem1, gef0, gef1, NR, 8 * ra - cb, 8 * rb - cb, ONE2, K2);
+                // lower edge blocks, t0 = -1: row 7's last cell is below the band; it hands on what the reference's skipped
+                // cells leave in its registers: H of row 6 at column 7, and the incoming E (-infinity)
+                if (t0 < 0) {
+                    XH[p][7] = bfi(LOm, XH[p][6], XH[p][7]);
+                    e[7] = bfi(LOm, NEG2, e[7]);
+                }
+                {
+                    uint16_t* dst_lo = xe_wave + lane + (2 * p) * (9 * 64);
+                    uint16_t* dst_hi = (p < P - 1) ? xe_wave + lane + (2 * p + 1) * (9 * 64) : xe_wave + lane + ((i & 1) ? S : S - 1) * (9 * 64);
+#pragma unroll
+                    for (int il = 0; il < 8; il++) { dst_lo[il * 64] = (uint16_t)e[il]; dst_hi[il * 64] = (uint16_t)(e[il] >> 16); }
+                    const uint32_t tagout = bfi(ACTm, rc, NOTAG);
+                    dst_lo[8 * 64] = (uint16_t)tagout; dst_hi[8 * 64] = (uint16_t)(tagout >> 16);
+                }
+                CORNER[p] = bfi(ACTm, rh[7], CORNER[p]);
+
+                // a half that has not started its column yet was computed on garbage: put its initial state back
+                // (inactive and not past the end of its column; a column that was started and then dropped by the slice
+                // limits never comes back, so resetting it as well does no harm)
+                const uint32_t RSm = ~ACTm & ~lt_mask(ce2, q2, F15);
+                if (__any(RSm != 0u)) {
+                    if (__builtin_expect(__any(RSm != 0u && (ra <= W || rb <= W)), 0)) {
+                        uint32_t ha[8], fa[8], ca, hb[8], fb[8], cbv;
+                        int ral = ra, rbl = rb;
+                        asm volatile("" : "+v"(ral), "+v"(rbl));
+                        init_half(ral, R, w, W, gapoe, ge, base, ha, fa, ca);
+                        init_half(rbl, R, w, W, gapoe, ge, base, hb, fb, cbv);
+#pragma unroll
+                        for (int m = 0; m < 8; m++) { H[p][m] = bfi(RSm, pk2(ha[m], hb[m]), H[p][m]); F[p][m] = bfi(RSm, pk2(fa[m], fb[m]), F[p][m]); }
+                        CORNER[p] = bfi(RSm, pk2(ca, cbv), CORNER[p]);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            H[p][m] = bfi(RSm, m < 7 ? HINIT : H7INIT, H[p][m]);
+                            F[p][m] = bfi(RSm, m == 0 ? F0INIT : FINIT, F[p][m]);
+                        }
+                        CORNER[p] = bfi(RSm, CINIT, CORNER[p]);
+                    }
+                }
+            }
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        // Prefetch for step i + 1 (see align_kernel.hip)
+        uint32_t rwn[S];                            // reference words of the columns that start next
+        uint32_t ADVM[P];                           // 0xFFFF: the slot leaves its column block after this step (q + 1 > ce)
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            ADVM[p] = alive ? ~lt_mask(pk_sub(I2, RC[p]), pk_min(pk_add(RC[p], W2), PQL1), F15) : 0u;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const uint32_t av = (s & 1) ? (ADVM[s >> 1] >> 31) : (ADVM[s >> 1] & 1u);
+            const int r = (int)((s & 1) ? (RC[s >> 1] >> 16) : (RC[s >> 1] & 0xffffu));
+            const int rn = av ? r + GS : r;
+            const int qn = i + 1 - rn;
+            uint32_t qv = 0u;
+            if (alive && qn >= 0 && qn < pql) qv = ((gptr_t)La->packed_q)[pq + (uint32_t)qn];
+            qcls[s] = class_word(qv);
+            rwn[s] = 0xEEEEEEEEu;
+            if (av && rn < prl) rwn[s] = ((gptr_t)La->packed_t)[pt + (uint32_t)rn];
+        }
+
+        // ---- hand-off: slot s feeds slot s + 1 (half swap inside a register pair, or the next register pair);
+        //      the last slot feeds slot 0 of the next lane ----
+        {
+            uint32_t th[8];
+#pragma unroll
+            for (int il = 0; il < 8; il++) th[il] = (uint32_t)lane_read((int)XH[P - 1][il], left_lane);
+#pragma unroll
+            for (int p = P - 1; p >= 0; p--) {
+#pragma unroll
+                for (int il = 0; il < 8; il++) {
+                    const uint32_t ph_ = (p > 0) ? XH[p > 0 ? p - 1 : 0][il] : th[il];
+                    XH[p][il] = __builtin_amdgcn_alignbit(XH[p][il], ph_, 16);     // low = previous pair's high half, high = own low half
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ anti-diagonals 8i..8i+7 are complete
+        bool stopped = false;
+        int vred[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) vred[x] = A[x] + x;        // see row_keys4
+        group_max8<G>(vred, lane);
+        int lo8 = vred[0], hi8 = vred[0];
+#pragma unroll
+        for (int x = 1; x < 8; x++) { lo8 = imin(lo8, vred[x]); hi8 = imax(hi8, vred[x]); }
+        // Fast path (wave-uniform): every anti-diagonal of this step has an in-band maximum well inside its zone, inside
+        // the pair, and within z of the running maximum, so neither z-drop nor the bail-out can fire.
+        bool calm = !final_step && (8 * i + 7 < lim);
+        {
+            const int lo_rep = lo8 >> K, lo_abs = lo_rep - r16::BIAS + base, hi_abs = (hi8 >> K) - r16::BIAS + base;
+            calm = calm && lo_rep >= bail_rep && lo_abs >= NEG_INF2 + spread && (z < 0 || imax(best, hi_abs) - lo_abs <= z);
+        }
+        if (__builtin_expect(__all(calm || !alive), 1)) {
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                const int Hv = (vred[x] >> K) - r16::BIAS + base;
+                if (alive && Hv > best) { best = Hv; best_t = (vred[x] & KMASK) + cb; best_q = 8 * i + x - best_t; }
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                const int v = vred[x];
+                const int d = 8 * i + x;
+                const bool chk = alive && !stopped && !bail && (final_step || d < lim);      // agatha_kernel.h:293-294 / 337
+                const int rep = v >> K;
+                int Hv = rep - r16::BIAS + base, c = (v & KMASK) + cb;
+                if (rep < r16::GLO) { Hv = -32768; c = 0; }                                // empty, or only out-of-band cells
+                else if (chk && (rep < bail_rep || Hv < NEG_INF2 + spread)) bail = true;
+                if (chk && !bail) {                                                        // agatha_kernel.h:297-309
+                    if (Hv > best) { best = Hv; best_t = c; best_q = d - c; }
+                    else if (c >= best_t && (d - c) >= best_q) {
+                        const int tlen = c - best_t, qlen = (d - c) - best_q;
+                        const int l = tlen > qlen ? tlen - qlen : qlen - tlen;
+                        if (z >= 0 && best - Hv > z + l * ge) stopped = true;
+                    }
+                }
+            }
+        }
+        bool finished = alive && (stopped || final_step);
+
+        // carry dl 8..14 into the next step
+#pragma unroll
+        for (int x = 0; x < 7; x++) A[x] = A[8 + x] + 8;        // anti-diagonal 8 + x of this step is x of the next
+#pragma unroll
+        for (int x = 7; x < 15; x++) A[x] = 0;
+
+        // ---- rebase: keep the representation of the running maximum small ----
+        {
+            const bool reb = alive && !finished && !bail && (hi8 >> K) > r16::REBASE;
+            if (__builtin_expect(__any(reb), 0)) {
+                const uint32_t D2 = reb ? dup2(r16::DELTA) : 0u;
+                const uint32_t CAP2 = dup2(r16::LO - 1);
+                // only in-band values follow the base: max(v - D, min(v, LO - 1)) is v - D for them, v for the rest
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+#pragma unroll
+                    for (int m = 0; m < 8; m++) {
+                        H[p][m] = pk_max(pk_sub(H[p][m], D2), pk_min(H[p][m], CAP2));
+                        F[p][m] = pk_max(pk_sub(F[p][m], D2), pk_min(F[p][m], CAP2));
+                        XH[p][m] = pk_max(pk_sub(XH[p][m], D2), pk_min(XH[p][m], CAP2));
+                    }
+                    CORNER[p] = pk_max(pk_sub(CORNER[p], D2), pk_min(CORNER[p], CAP2));
+                }
+                // the E hand-off values of this lane in LDS (all regions; the ones not in flight are dead)
+                {
+                    const int dl = reb ? r16::DELTA : 0;
+                    uint16_t* xe_my = xe_wave + lane;
+                    for (int g = 0; g < (S + 1) * 9; g++) {
+                        if (g % 9 == 8) continue;       // the tag row
+                        const int v = (int)xe_my[g * 64];
+                        xe_my[g * 64] = (uint16_t)imax(v - dl, imin(v, r16::LO - 1));
+                    }
+                }
+                const int dk = reb ? (r16::DELTA << K) : 0, capk = (r16::LO << K) - 1;
+#pragma unroll
+                for (int x = 0; x < 7; x++) A[x] = imax(A[x] + x - dk, imin(A[x] + x, capk)) - x;
+                if (reb) base += r16::DELTA;
+            }
+        }
+
+        // slots whose column block has left the band move on to column r + G*S (always beyond the first band width)
+        {
+            uint32_t anyadv = 0u;
+#pragma unroll
+            for (int p = 0; p < P; p++) anyadv |= ADVM[p];
+            if (__any(anyadv != 0u)) {
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const uint32_t ADm = ADVM[p];
+                    if (ADm != 0u) {
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            H[p][m] = bfi(ADm, m < 7 ? HINIT : H7INIT, H[p][m]);
+                            F[p][m] = bfi(ADm, m == 0 ? F0INIT : FINIT, F[p][m]);
+                        }
+                        CORNER[p] = bfi(ADm, CINIT, CORNER[p]);
+                        RC[p] = pk_add(RC[p], ADm & dup2((uint32_t)GS));
+                        if (ADm & 1u) build_profile5(prof0 + (2 * p) * (4 * 64), rwn[2 * p], Pm.match, Pm.mismatch);
+                        if (ADm >> 31) build_profile5(prof0 + (2 * p + 1) * (4 * 64), rwn[2 * p + 1], Pm.match, Pm.mismatch);
+                    }
+                }
+            }
+        }
+
+        // next step / next slice (agatha_kernel.h:183-191, 330-334)
+        i++; y++;
+        if (y == sw) {
+            y = 0;
+            if (i >= total) final_step = true;
+            else {
+                ss = imax(imax(0, i - pql + 1), ((i * 8 + 8 - w) / 2) / 8);
+                se = imin(imin(prl - 1, i + sw - 1), (((i + sw - 1) * 8 + 7 + w) / 2) / 8);
+                if (ss > se) finished = alive;       // empty slice: stop without checking it (:189-191)
+            }
+        }
+        if (__builtin_expect(bail && alive, 0)) {
+            // hand the pair to the int32 kernel (launched after this one on the same stream)
+            if (k == 0) La->exotic[pair] = 2;
+            alive = false;
+        } else if (__builtin_expect(finished, 0)) {
+            if (k == 0) { La->score[pair] = best; La->qend[pair] = best_q; La->tend[pair] = best_t; }   // :359-363
+            alive = false;
+        }
+        }   // step
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+template <int G, int P>
+static hipError_t launch_align16_t(const AlignLaunch& L, hipStream_t st)
+{
+    const int groups_per_block = (256 / 64) * (64 / G);
+    int blocks = (L.n + groups_per_block - 1) / groups_per_block;
+    int max_blocks = L.num_cus * 2;
+    if (L.max_blocks_override > 0) max_blocks = L.max_blocks_override;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((align16_kernel<G, P>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
+    return hipGetLastError();
+}
+
+struct Cfg16 { int G, P; hipError_t (*fn)(const AlignLaunch&, hipStream_t); };
+static const Cfg16 kCfgs16[] = {       // ascending G * 2P
+    {16, 3, launch_align16_t<16, 3>},
+};
+
+bool agatha16_scores_ok(const AlignParams& p)
+{
+    if (p.band_width < 16) return false;
+    const int W = (p.band_width + 7) / 8, t0 = p.band_width - 8 * W;
+    if (t0 < -1) return false;
+    if (p.match < 0 || p.match > 16 || p.mismatch < 0 || p.mismatch > 32) return false;
+    if (p.gap_open < 0 || p.gap_open > 64 || p.gap_extend < 0 || p.gap_extend > 16) return false;
+    int per = 2 * p.gap_extend; if (p.mismatch > per) per = p.mismatch; if (per < 1) per = 1;
+    const int spread = p.gap_open + p.gap_extend + per * (p.band_width + 16) + 64;
+    return spread <= 6000;
+}
+
+// true if a packed-int16 configuration exists for this window; launches it (kind-0 pairs only)
+bool launch_align16(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st, hipError_t* err)
+{
+    *err = hipSuccess;
+    if (!agatha16_scores_ok(L.p)) return false;
+    for (const Cfg16& c : kCfgs16) {
+        if (c.G * 2 * c.P >= window_blocks && c.G * 2 * c.P <= 2 * window_blocks + 32) {
+            if (G_out) *G_out = c.G;
+            if (S_out) *S_out = 2 * c.P;
+            *err = c.fn(L, st);
+            return true;
+        }
+    }
+    return false;
+}
+
+bool align16_available(const AlignParams& p, int window_blocks)
+{
+    if (!agatha16_scores_ok(p)) return false;
+    for (const Cfg16& c : kCfgs16)
+        if (c.G * 2 * c.P >= window_blocks && c.G * 2 * c.P <= 2 * window_blocks + 32) return true;
+    return false;
+}
+
+}  // namespace agatha

@@ -25,51 +25,9 @@
 #include <limits.h>
 
 #include "kernels.h"
+#include "device_common.h"
 
 namespace agatha {
-
-#define NEG_INF2 (-16384)   // SHRT_MIN/2: the reference's -infinity (gasal_kernels.h:39)
-#define N_VALUE 14u         // 'N' & 0xF (AGAThA/Makefile:4)
-
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
-__device__ __forceinline__ int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
-
-// value of lane `src` (absolute lane id) -- ds_bpermute_b32, no LDS storage involved
-__device__ __forceinline__ int lane_read(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
-
-// max over the G lanes of a group of eight values at once, result in every lane: DPP row rotations inside a 16-lane
-// row, then all cross-row ds_bpermutes are issued before the first one is waited for
-template <int G>
-__device__ __forceinline__ void group_max8(int (&v)[8], int lane)
-{
-#pragma unroll
-    for (int x = 0; x < 8; x++) {
-        v[x] = imax(v[x], __builtin_amdgcn_update_dpp(INT_MIN, v[x], 0x121, 0xf, 0xf, true));
-        v[x] = imax(v[x], __builtin_amdgcn_update_dpp(INT_MIN, v[x], 0x122, 0xf, 0xf, true));
-        v[x] = imax(v[x], __builtin_amdgcn_update_dpp(INT_MIN, v[x], 0x124, 0xf, 0xf, true));
-        v[x] = imax(v[x], __builtin_amdgcn_update_dpp(INT_MIN, v[x], 0x128, 0xf, 0xf, true));
-    }
-    if (G >= 32) {
-        int o[8];
-#pragma unroll
-        for (int x = 0; x < 8; x++) o[x] = lane_read(v[x], lane ^ 16);
-#pragma unroll
-        for (int x = 0; x < 8; x++) v[x] = imax(v[x], o[x]);
-    }
-    if (G >= 64) {
-        int o[8];
-#pragma unroll
-        for (int x = 0; x < 8; x++) o[x] = lane_read(v[x], lane ^ 32);
-#pragma unroll
-        for (int x = 0; x < 8; x++) v[x] = imax(v[x], o[x]);
-    }
-}
-
-template <int GS> struct KeyBits {          // smallest K with 2^K >= 8 * (GS + 2)
-    static constexpr int value = (8 * (GS + 2) <= 128) ? 7 : (8 * (GS + 2) <= 256) ? 8 : (8 * (GS + 2) <= 512) ? 9
-                               : (8 * (GS + 2) <= 1024) ? 10 : (8 * (GS + 2) <= 2048) ? 11 : (8 * (GS + 2) <= 4096) ? 12 : 13;
-};
 
 // initial column state of column block r: H(-1, c), F(0, c)  (agatha_kernel.h:133-148, 207-215)
 __device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge, int neg, int (&h)[8], int (&f)[8], int& corner)
@@ -190,12 +148,6 @@ __device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, 
 
 // Score profile of one column block: rows of 8 signed bytes (even columns in .x, odd in .y, column 0/1 in the top
 // byte) for the query-base classes 0..3 = A, C, T, G and 7 = N.  SWAR on the 8 packed reference codes.
-__device__ __forceinline__ uint32_t eq_bytes(uint32_t R, uint32_t code4)       // 0xFF in every byte where R == code
-{
-    const uint32_t X = R ^ code4;
-    const uint32_t ne = ((X + 0x7F7F7F7Fu) & 0x80808080u) >> 7;                // 1 where the byte differs (codes <= 15)
-    return (ne ^ 0x01010101u) * 0xFFu;
-}
 __device__ __forceinline__ void build_profile(uint2* __restrict__ prof, uint32_t rword, int a, int b)
 {
     const uint32_t Re = (rword >> 4) & 0x0F0F0F0Fu, Ro = rword & 0x0F0F0F0Fu;  // columns 0,2,4,6 / 1,3,5,7
@@ -268,7 +220,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
         const bool need = !alive && !exhausted;
         if (__builtin_expect(__any(need), 0)) {
             int idx = 0;
-            if (need && k == 0) idx = (int)atomicAdd(La->queue + (CMP ? 1 : 0), 1u);
+            if (need && k == 0) idx = (int)atomicAdd(La->queue + (CMP ? 2 : 1), 1u);
             idx = lane_read(idx, gbase);
             if (need) {
                 if (idx >= La->n) exhausted = true;
@@ -276,8 +228,11 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                     pair = (int)La->order[idx];
                     // two launches share the work: this instantiation only takes the pairs of its kind (the profile
                     // kernel skips pairs with letters outside ACGTN, the compare kernel takes exactly those)
-                    const bool wants_cmp = La->force_cmp || (La->exotic[pair] != 0);
-                    if (wants_cmp == CMP) {
+                    // pair kinds: 0 = plain letters, 1 = letters outside ACGTN (compare kernel), 2 = handed over by the
+                    // packed-int16 kernel.  The int16 kernel (when launched, use16) takes kind 0.
+                    const int kind = La->exotic[pair];
+                    const bool mine = CMP ? (La->force_cmp || kind == 1) : (kind == 2 || (kind == 0 && !La->use16));
+                    if (mine) {
                     Q = (int)La->qlens[pair]; R = (int)La->tlens[pair];
                     pq = (gptr_t)(La->packed_q + (La->qoffs[pair] >> 3));
                     pt = (gptr_t)(La->packed_t + (La->toffs[pair] >> 3));
@@ -314,7 +269,10 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                 }
             }
         }
-        if (!__any(alive)) break;
+        if (!__any(alive)) {
+            if (__all(exhausted)) break;
+            continue;                              // every group drew a pair of the other kind: draw again
+        }
 
         // ------------------------------------------------------------------ one step
         // column base of the packed maxima: one block left of the lowest active column block
@@ -565,6 +523,17 @@ __device__ __forceinline__ bool word_is_plain(uint32_t v)
     return ok;
 }
 
+// true if one of the first `nbases` (1..8) bases of the packed word is N
+__device__ __forceinline__ bool word_has_n(uint32_t v, uint32_t nbases)
+{
+    bool has = false;
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < 8; k2++) has = has || (k2 < nbases && ((v >> (28 - 4 * k2)) & 15u) == N_VALUE);
+    return has;
+}
+
+// kind of each pair: 1 = a sequence holds a letter outside {A, C, G, T, N} (compare kernel); 2 = the QUERY holds an N
+// (the packed-int16 kernel's score profile has no row for it: int32 profile kernel); 0 = everything else
 __global__ void __launch_bounds__(256)
 exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__ packed_t,
               const uint32_t* __restrict__ qlens, const uint32_t* __restrict__ tlens,
@@ -573,15 +542,19 @@ exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict_
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int p = wave; p < n; p += nwaves) {
-        bool plain = true;
+        bool plain = true, qn = false;
         const uint32_t* a = packed_q + (qoffs[p] >> 3);
-        const uint32_t na = (qlens[p] + 7u) >> 3;
-        for (uint32_t i = lane; i < na; i += 64u) plain = plain && word_is_plain(a[i]);
+        const uint32_t ql = qlens[p], na = (ql + 7u) >> 3;
+        for (uint32_t i = lane; i < na; i += 64u) {
+            const uint32_t v = a[i];
+            plain = plain && word_is_plain(v);
+            qn = qn || word_has_n(v, (i + 1u < na) ? 8u : ql - 8u * i);
+        }
         const uint32_t* b = packed_t + (toffs[p] >> 3);
         const uint32_t nb = (tlens[p] + 7u) >> 3;
         for (uint32_t i = lane; i < nb; i += 64u) plain = plain && word_is_plain(b[i]);
-        const bool all_plain = __all(plain);
-        if (lane == 0) exotic[p] = all_plain ? 0 : 1;
+        const bool all_plain = __all(plain), any_qn = __any(qn);
+        if (lane == 0) exotic[p] = all_plain ? (any_qn ? 2 : 0) : 1;
     }
 }
 
@@ -688,7 +661,7 @@ int key_bits_for_window(int window_blocks)
     return -1;
 }
 
-__global__ void record_kernel(AlignLaunch L, AlignLaunch* rec) { *rec = L; L.queue[0] = 0u; L.queue[1] = 0u; }
+__global__ void record_kernel(AlignLaunch L, AlignLaunch* rec) { *rec = L; L.queue[0] = 0u; L.queue[1] = 0u; L.queue[2] = 0u; }
 
 hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st)
 {

@@ -10,7 +10,7 @@
 namespace {
 
 thread_local char g_err[256] = "";
-thread_local int g_lastG = 0, g_lastS = 0;
+thread_local int g_lastG = 0, g_lastS = 0, g_last16 = 0;
 thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 
 int hip_fail(hipError_t e, const char* what)
@@ -138,9 +138,20 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.force_cmp = (sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     HIPCHK(agatha::launch_exotic(L, st));
     { const char* e = getenv("AGATHA_AMD_MAX_BLOCKS"); L.max_blocks_override = e ? atoi(e) : 0; }
+    // the packed-int16 kernel takes the plain pairs first when the scores and the band allow it
+    // (AGATHA_AMD_NO_INT16=1 keeps everything on the int32 kernels: A/B runs, debugging)
+    { const char* e = getenv("AGATHA_AMD_NO_INT16");
+      L.use16 = (!L.force_cmp && !(e && atoi(e)) && agatha::align16_available(L.p, (int)window)) ? 1 : 0; }
     L.self_dev = rec;
     HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record + queue head reset, stream-ordered
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));
+    g_last16 = 0;
+    if (L.use16) {
+        hipError_t e16 = hipSuccess;
+        int G16 = 0, S16 = 0;
+        if (agatha::launch_align16(L, (int)window, &G16, &S16, st, &e16)) g_last16 = (G16 << 8) | S16;
+        HIPCHK(e16);
+    }
     HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st));
     if (g_ev1) HIPCHK(hipEventRecord(g_ev1, st));
     return 0;
@@ -149,6 +160,8 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
 void agatha_amd_set_kernel_events(void* ev_begin, void* ev_end) { g_ev0 = (hipEvent_t)ev_begin; g_ev1 = (hipEvent_t)ev_end; }
 
 void agatha_amd_last_config(int* G, int* S) { if (G) *G = g_lastG; if (S) *S = g_lastS; }
+
+int agatha_amd_last_int16_config(void) { return g_last16; }
 
 int agatha_amd_malloc(void** d_ptr, size_t bytes) { if (!d_ptr) return AGATHA_AMD_EINVAL; HIPCHK(hipMalloc(d_ptr, bytes ? bytes : 1)); return 0; }
 int agatha_amd_free(void* d_ptr) { if (d_ptr) HIPCHK(hipFree(d_ptr)); return 0; }

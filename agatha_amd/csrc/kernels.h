@@ -12,7 +12,9 @@ struct AlignLaunch {
     const uint32_t *packed_q, *packed_t, *qlens, *tlens, *qoffs, *toffs, *order;
     int n;
     unsigned int* queue;
-    uint8_t* exotic;               // per pair: 1 = holds letters outside ACGTN (compare path)
+    uint8_t* exotic;               // per pair kind: 0 = plain, 1 = holds letters outside ACGTN (compare kernel),
+                                   // 2 = abandoned by the packed-int16 kernel (int32 profile kernel takes it)
+    int use16;                     // 1 = the packed-int16 kernel runs first and takes the kind-0 pairs
     int force_cmp;                 // 1 = scores do not fit the byte profile: compare path for every pair
     int32_t *score, *qend, *tend;
     AlignParams p;
@@ -24,6 +26,9 @@ struct AlignLaunch {
 // window_blocks = blocks that can be live on one block-anti-diagonal; picks the smallest (G, S) covering it
 hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st);
 int max_window_blocks();
+// packed-int16 kernel (align16_kernel.hip): usable for these scores / this window?  launch (kind-0 pairs only)
+bool align16_available(const AlignParams& p, int window_blocks);
+bool launch_align16(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st, hipError_t* err);
 int key_bits_for_window(int window_blocks);
 // writes L into *rec on the device (by-value kernel argument: no host-memory lifetime to care about) and zeroes *L.queue
 hipError_t launch_exotic(const AlignLaunch& L, hipStream_t st);

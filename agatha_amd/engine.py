@@ -74,6 +74,7 @@ def load_library():
     lib.agatha_amd_set_kernel_events.restype = None
     lib.agatha_amd_last_config.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.agatha_amd_last_config.restype = None
+    lib.agatha_amd_last_int16_config.restype = C.c_int
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.agatha_amd_free.argtypes = [vp]
     lib.agatha_amd_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -95,7 +96,7 @@ def load_library():
 EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack",
-    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -240,6 +241,11 @@ class Engine:
         g, s = C.c_int(0), C.c_int(0)
         self.lib.agatha_amd_last_config(C.byref(g), C.byref(s))
         return g.value, s.value
+
+    def last_int16_config(self):
+        """(lanes per pair, slots per lane) of the packed-int16 kernel if the last align launched it, else None."""
+        v = int(self.lib.agatha_amd_last_int16_config())
+        return (v >> 8, v & 255) if v else None
 
     def batch(self, qbuf, tbuf, qoff, toff, qlen, tlen):
         return DeviceBatch(self, qbuf, tbuf, qoff, toff, qlen, tlen)

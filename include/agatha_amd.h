@@ -94,6 +94,11 @@ void agatha_amd_set_kernel_events(void* ev_begin, void* ev_end);
 /* lane-group shape the last agatha_amd_align() of this thread used (diagnostics for bench.py / DESIGN.md) */
 void agatha_amd_last_config(int* lanes_per_pair, int* slots_per_lane);
 
+/* (lanes_per_pair << 8) | slots_per_lane of the packed-int16 kernel if the last agatha_amd_align() of this thread
+ * launched it (plain-letter pairs run there first; pairs it hands back and pairs with other letters run on the int32
+ * kernels), 0 if it did not.  AGATHA_AMD_NO_INT16=1 in the environment keeps every pair on the int32 kernels. */
+int agatha_amd_last_int16_config(void);
+
 /* Thin device-memory helpers so that non-HIP hosts (ctypes, cgo, JNI) can drive the library without
  * linking the HIP runtime themselves.  Synchronous except the *_async copies. */
 int agatha_amd_malloc(void** d_ptr, size_t bytes);

@@ -311,7 +311,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
     int i = 0, y = 0, final = 0, cb_prev = 0;
     int ss = 0, se = imin(imin(prl - 1, sw - 1), ((sw - 1) * 8 + 7 + w) / 2 / 8);
     int32_t vmin = 0, vmax = 0, gmax = INT_MIN, rmin = INT_MAX;
-#define REB(v) ((v) >= L16_LO ? (v) - L16_DELTA : (v))      /* only in-band values follow the base */
+#define REB(v) imax((v) - L16_DELTA, imin((v), L16_LO - 1))   /* only in-band values follow the base (v_pk_max / v_pk_min form of the kernel) */
 #define TRACK(v) do { if ((v) < vmin) vmin = (v); if ((v) > vmax) vmax = (v); } while (0)
 
     for (;;) {
@@ -433,7 +433,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 }
                 for (int s = 0; s <= S; s++)
                     for (int m = 0; m < 8; m++) { ln->xh[s][m] = REB(ln->xh[s][m]); ln->xe[s][m] = REB(ln->xe[s][m]); }
-                for (int x = 0; x < 7; x++) if (ln->A[x] != INT_MIN) ln->A[x] -= L16_DELTA << K;
+                for (int x = 0; x < 7; x++) if (ln->A[x] != INT_MIN) ln->A[x] = imax(ln->A[x] - (L16_DELTA << K), imin(ln->A[x], ((L16_LO + 32768) << K) - 1 - (32768 << K)));
             }
         }
         for (int k = 0; k < G; k++)
