@@ -348,7 +348,11 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
         }
         if (!__any(alive)) {
             if (__all(exhausted)) break;           // else every group drew a pair of another kind: draw again
-        } else {
+            continue;
+        }
+        // The steps run in an inner loop of their own, left only when a group wants a new pair: with the queue code
+        // inside the same loop the register allocator copied ~200 registers per step between two sets.
+        do {
 
         // ------------------------------------------------------------------ one step
         const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
@@ -666,7 +670,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
             if (k == 0) { La->score[pair] = best; La->qend[pair] = best_q; La->tend[pair] = best_t; }   // :359-363
             alive = false;
         }
-        }   // step
+        } while (!__any(!alive && !exhausted));
     }
 }
 
