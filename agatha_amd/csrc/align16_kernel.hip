@@ -91,18 +91,25 @@ __device__ __forceinline__ void init_half(int r, int R, int w, int W, int gapoe,
 }
 
 // Score profile of one column block, four rows of 8 signed bytes (even columns in .x, odd in .y, column 0/1 in the
-// top byte): query-base classes 0..3 = A, C, T, G.
-__device__ __forceinline__ void build_profile5(uint2* __restrict__ prof, uint32_t rword, int a, int b)
+// top byte): query-base classes 0..3 = A, C, T, G.  One v_perm_b32 per word: the class (code >> 1) & 7 of each reference
+// base (A 0, C 1, T 2, G 3, N 7) selects a byte of an 8-entry table {match at the query's own class, -mismatch
+// elsewhere, -1 for N}.  lut_hi = entries 4..7, lut[c] = entries 0..3 of query class c.
+struct ProfileLut { uint32_t hi, lo[4]; };
+__device__ __forceinline__ ProfileLut make_profile_lut(int a, int b)
 {
-    const uint32_t Re = (rword >> 4) & 0x0F0F0F0Fu, Ro = rword & 0x0F0F0F0Fu;
-    const uint32_t A4 = ((uint32_t)a & 0xFFu) * 0x01010101u, NB4 = ((uint32_t)(-b) & 0xFFu) * 0x01010101u;
-    const uint32_t BMe = NB4 | eq_bytes(Re, 0x0E0E0E0Eu), BMo = NB4 | eq_bytes(Ro, 0x0E0E0E0Eu);   // -b, or -1 where ref is N
-    const uint32_t codes[4] = {0x01010101u, 0x03030303u, 0x04040404u, 0x07070707u};              // A C T G
+    ProfileLut t;
+    const uint32_t nb = (uint32_t)(-b) & 0xFFu, ma = (uint32_t)a & 0xFFu;
+    t.hi = 0xFF000000u | (nb * 0x00010101u);
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const uint32_t me = eq_bytes(Re, codes[c]), mo = eq_bytes(Ro, codes[c]);
-        prof[c * 64] = make_uint2((A4 & me) | (BMe & ~me), (A4 & mo) | (BMo & ~mo));
-    }
+    for (int c = 0; c < 4; c++) t.lo[c] = ((nb * 0x01010101u) & ~(0xFFu << (8 * c))) | (ma << (8 * c));
+    return t;
+}
+__device__ __forceinline__ void build_profile5(uint2* __restrict__ prof, uint32_t rword, const ProfileLut& t)
+{
+    const uint32_t se = (rword >> 5) & 0x07070707u, so = (rword >> 1) & 0x07070707u;     // columns 0,2,4,6 / 1,3,5,7
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        prof[c * 64] = make_uint2(__builtin_amdgcn_perm(t.hi, t.lo[c], se), __builtin_amdgcn_perm(t.hi, t.lo[c], so));
 }
 
 // packed query word -> class index per nibble: A(1)->0 C(3)->1 T(4)->2 G(7)->3.  Pairs with N in the query are not
@@ -193,19 +200,19 @@ template <int K>
 __device__ __forceinline__ void block_pair16(uint32_t (&h)[8], uint32_t (&f)[8], uint32_t corner, const uint32_t (&rh)[8],
                                              uint32_t (&e)[8], uint32_t (&oh)[8], int (&A)[15], uint32_t qc_lo, uint32_t qc_hi,
                                              const uint2* __restrict__ pl, const uint2* __restrict__ ph, uint32_t gapo2,
-                                             uint32_t ge2, uint32_t gee0, uint32_t geem1, uint32_t gef0, uint32_t gef1, uint32_t NR,
-                                             int crel_lo, int crel_hi, uint32_t one2, uint32_t k2)
+                                             uint32_t ge2, uint32_t gee0, uint32_t geem1, uint32_t gef0, uint32_t gef1, uint32_t NRK,
+                                             int crel_lo, int crel_hi)
 {
     // profile rows are requested while the previous row's cells are being computed
-    uint2 wl = pl[((qc_lo >> 28) & 3u) * 64u], wh = ph[((qc_hi >> 28) & 3u) * 64u];
+    uint2 wl = pl[__builtin_amdgcn_ubfe(qc_lo, 28, 2) * 64u], wh = ph[__builtin_amdgcn_ubfe(qc_hi, 28, 2) * 64u];
 #pragma unroll
     for (int il = 0; il < 8; il++) {
-        // key multiplier of this row: 2^K where the row exists, 0 where it does not
-        const uint32_t kmul = pk_shl_c(pk_min_c(pk_sub_sat_c(NR, dup2((uint32_t)il)), one2), k2);
+        // key multiplier of this row: 2^K where the row exists (il < rows), 0 where it does not
+        const uint32_t kmul = pk_min_c(pk_sub_sat_c(NRK, dup2((uint32_t)(il << K))), dup2(1u << K));
         row_add_scores(h, il == 0 ? corner : rh[il > 0 ? il - 1 : 0], wl, wh);
         if (il < 7) {
-            wl = pl[((qc_lo >> (24 - 4 * il)) & 3u) * 64u];
-            wh = ph[((qc_hi >> (24 - 4 * il)) & 3u) * 64u];
+            wl = pl[__builtin_amdgcn_ubfe(qc_lo, 24 - 4 * il, 2) * 64u];
+            wh = ph[__builtin_amdgcn_ubfe(qc_hi, 24 - 4 * il, 2) * 64u];
         }
         uint32_t ev = e[il];
         // per-cell gap-extension operands: cell diagonal jl - il == 0 / -1 (E) and 0 / +1 (F) may be cut
@@ -264,6 +271,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
     const uint32_t GAPO2 = dup2((uint32_t)gapo), GE2 = dup2((uint32_t)ge), CUT2 = dup2(r16::CUT);
     const uint32_t NEG2 = dup2(r16::NEG), OUT2 = dup2(r16::OUT), ONE2 = 0x00010001u, K2 = dup2(K), F15 = 0x000F000Fu;
     const uint32_t W2 = dup2((uint32_t)W), NOTAG = 0xFFFEFFFEu;
+    const ProfileLut plut = make_profile_lut(Pm.match, Pm.mismatch);
     // initial state of a column block beyond the first band width (init_half with r > W): constants per column
     const uint32_t HINIT = (t0 < 0) ? OUT2 : OUT2, H7INIT = NEG2;     // h[m], m < 7: the cell it is the diagonal of, (0, m+1), is outside for t0 <= 0
     const uint32_t F0INIT = (0 > t0) ? OUT2 : NEG2, FINIT = OUT2, CINIT = (0 > t0) ? OUT2 : NEG2;
@@ -280,7 +288,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
     uint32_t RC[P];                                 // column block of each slot
     uint32_t H[P][8], F[P][8], CORNER[P];
     uint32_t XH[P][8];                              // row hand-off of H (registers); E goes through s_xe
-    uint32_t qcls[S];
+    uint32_t qcls[S];                               // packed query word of the row block each slot works on this step
     int A[15];
 
 #pragma unroll
@@ -326,7 +334,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
                             for (int hf = 0; hf < 2; hf++) {
                                 const int r = ra + hf, s = 2 * p + hf;
                                 const uint32_t rw0 = (r < prl) ? ((gptr_t)La->packed_t)[pt + (uint32_t)r] : 0xEEEEEEEEu;
-                                build_profile5(prof0 + s * (4 * 64), rw0, Pm.match, Pm.mismatch);
+                                build_profile5(prof0 + s * (4 * 64), rw0, plut);
                             }
                         }
 #pragma unroll
@@ -383,6 +391,12 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
                 // regular edge blocks: q == r - W (upper, cut on cell diagonal t0), q == r + W (lower, cut on -t0);
                 // every other block is uncut when t0 is 0 or -1
                 const uint32_t UPm = eq_mask(pk_add(q2, W2), rc, ONE2) & ACTm, LOm = eq_mask(q2, pk_add(rc, W2), ONE2) & ACTm;
+                // slots that leave their column block after this step (q + 1 > ce) move on to column r + G*S: the reference
+                // word of the new column is requested now and used after the block
+                const uint32_t ADm = alive ? ~lt_mask(q2, ce2, F15) : 0u;
+                uint32_t rwa = 0xEEEEEEEEu, rwb = 0xEEEEEEEEu;
+                if ((ADm & 1u) && ra + GS < prl) rwa = ((gptr_t)La->packed_t)[pt + (uint32_t)(ra + GS)];
+                if ((ADm >> 31) && rb + GS < prl) rwb = ((gptr_t)La->packed_t)[pt + (uint32_t)(rb + GS)];
 
                 if (__builtin_expect(y == 0 && ACTm != 0u && (ra == prl - 1 || rb == prl - 1), 0)) {
                     // pass start: padded ref columns fall back to -infinity (agatha_kernel.h:207-215); where the value
@@ -463,8 +477,8 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
                 // rows that exist: 8, fewer in the last row block, 0 for an inactive half
                 const uint32_t NR = bfi(eq_mask(q2, PQL1, ONE2), NRLAST, 0x00080008u) & ACTm;
 
-                block_pair16<K>(H[p], F[p], corner_in, rh, e, XH[p], A, qcls[2 * p], qcls[2 * p + 1], prof0 + (2 * p) * (4 * 64),
-                                prof0 + (2 * p + 1) * (4 * 64), GAPO2, GE2, gee0, geem1, gef0, gef1, NR, 8 * ra - cb, 8 * rb - cb, ONE2, K2);
+                block_pair16<K>(H[p], F[p], corner_in, rh, e, XH[p], A, class_word(qcls[2 * p]), class_word(qcls[2 * p + 1]), prof0 + (2 * p) * (4 * 64),
+                                prof0 + (2 * p + 1) * (4 * 64), GAPO2, GE2, gee0, geem1, gef0, gef1, pk_shl_c(NR, K2), 8 * ra - cb, 8 * rb - cb);
                 // lower edge blocks, t0 = -1: row 7's last cell is below the band; it hands on what the reference's skipped
                 // cells leave in its registers: H of row 6 at column 7, and the incoming E (-infinity)
                 if (t0 < 0) {
@@ -483,9 +497,11 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
 
                 // a half that has not started its column yet was computed on garbage: put its initial state back
                 // (inactive and not past the end of its column; a column that was started and then dropped by the slice
-                // limits never comes back, so resetting it as well does no harm)
+                // limits never comes back, so resetting it as well does no harm); a half that moves on starts from the
+                // same constants (its new column is always beyond the first band width)
                 const uint32_t RSm = ~ACTm & ~lt_mask(ce2, q2, F15);
-                if (__any(RSm != 0u)) {
+                const uint32_t INm = RSm | ADm;
+                if (__any(INm != 0u)) {
                     if (__builtin_expect(__any(RSm != 0u && (ra <= W || rb <= W)), 0)) {
                         uint32_t ha[8], fa[8], ca, hb[8], fb[8], cbv;
                         int ral = ra, rbl = rb;
@@ -495,38 +511,40 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
 #pragma unroll
                         for (int m = 0; m < 8; m++) { H[p][m] = bfi(RSm, pk2(ha[m], hb[m]), H[p][m]); F[p][m] = bfi(RSm, pk2(fa[m], fb[m]), F[p][m]); }
                         CORNER[p] = bfi(RSm, pk2(ca, cbv), CORNER[p]);
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            H[p][m] = bfi(ADm, m < 7 ? HINIT : H7INIT, H[p][m]);
+                            F[p][m] = bfi(ADm, m == 0 ? F0INIT : FINIT, F[p][m]);
+                        }
+                        CORNER[p] = bfi(ADm, CINIT, CORNER[p]);
                     } else {
 #pragma unroll
                         for (int m = 0; m < 8; m++) {
-                            H[p][m] = bfi(RSm, m < 7 ? HINIT : H7INIT, H[p][m]);
-                            F[p][m] = bfi(RSm, m == 0 ? F0INIT : FINIT, F[p][m]);
+                            H[p][m] = bfi(INm, m < 7 ? HINIT : H7INIT, H[p][m]);
+                            F[p][m] = bfi(INm, m == 0 ? F0INIT : FINIT, F[p][m]);
                         }
-                        CORNER[p] = bfi(RSm, CINIT, CORNER[p]);
+                        CORNER[p] = bfi(INm, CINIT, CORNER[p]);
                     }
+                }
+                if (__any(ADm != 0u)) {
+                    if (ADm & 1u) build_profile5(prof0 + (2 * p) * (4 * 64), rwa, plut);
+                    if (ADm >> 31) build_profile5(prof0 + (2 * p + 1) * (4 * 64), rwb, plut);
+                    RC[p] = pk_add(rc, ADm & dup2((uint32_t)GS));
+                }
+                // query words of the row blocks this pair of slots works on in step i + 1: requested now, used a step
+                // later (raw: converting them here would wait for the load)
+                {
+                    const uint32_t rcn = RC[p];
+                    const int qna = i + 1 - (int)(rcn & 0xffffu), qnb = i + 1 - (int)(rcn >> 16);
+                    uint32_t qva = 0u, qvb = 0u;
+                    if (alive && qna >= 0 && qna < pql) qva = ((gptr_t)La->packed_q)[pq + (uint32_t)qna];
+                    if (alive && qnb >= 0 && qnb < pql) qvb = ((gptr_t)La->packed_q)[pq + (uint32_t)qnb];
+                    qcls[2 * p] = qva; qcls[2 * p + 1] = qvb;
                 }
             }
         }
 
         __builtin_amdgcn_sched_barrier(0);
-        // Prefetch for step i + 1 (see align_kernel.hip)
-        uint32_t rwn[S];                            // reference words of the columns that start next
-        uint32_t ADVM[P];                           // 0xFFFF: the slot leaves its column block after this step (q + 1 > ce)
-#pragma unroll
-        for (int p = 0; p < P; p++)
-            ADVM[p] = alive ? ~lt_mask(pk_sub(I2, RC[p]), pk_min(pk_add(RC[p], W2), PQL1), F15) : 0u;
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            const uint32_t av = (s & 1) ? (ADVM[s >> 1] >> 31) : (ADVM[s >> 1] & 1u);
-            const int r = (int)((s & 1) ? (RC[s >> 1] >> 16) : (RC[s >> 1] & 0xffffu));
-            const int rn = av ? r + GS : r;
-            const int qn = i + 1 - rn;
-            uint32_t qv = 0u;
-            if (alive && qn >= 0 && qn < pql) qv = ((gptr_t)La->packed_q)[pq + (uint32_t)qn];
-            qcls[s] = class_word(qv);
-            rwn[s] = 0xEEEEEEEEu;
-            if (av && rn < prl) rwn[s] = ((gptr_t)La->packed_t)[pt + (uint32_t)rn];
-        }
-
         // ---- hand-off: slot s feeds slot s + 1 (half swap inside a register pair, or the next register pair);
         //      the last slot feeds slot 0 of the next lane ----
         {
@@ -624,30 +642,6 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
 #pragma unroll
                 for (int x = 0; x < 7; x++) A[x] = imax(A[x] + x - dk, imin(A[x] + x, capk)) - x;
                 if (reb) base += r16::DELTA;
-            }
-        }
-
-        // slots whose column block has left the band move on to column r + G*S (always beyond the first band width)
-        {
-            uint32_t anyadv = 0u;
-#pragma unroll
-            for (int p = 0; p < P; p++) anyadv |= ADVM[p];
-            if (__any(anyadv != 0u)) {
-#pragma unroll
-                for (int p = 0; p < P; p++) {
-                    const uint32_t ADm = ADVM[p];
-                    if (ADm != 0u) {
-#pragma unroll
-                        for (int m = 0; m < 8; m++) {
-                            H[p][m] = bfi(ADm, m < 7 ? HINIT : H7INIT, H[p][m]);
-                            F[p][m] = bfi(ADm, m == 0 ? F0INIT : FINIT, F[p][m]);
-                        }
-                        CORNER[p] = bfi(ADm, CINIT, CORNER[p]);
-                        RC[p] = pk_add(RC[p], ADm & dup2((uint32_t)GS));
-                        if (ADm & 1u) build_profile5(prof0 + (2 * p) * (4 * 64), rwn[2 * p], Pm.match, Pm.mismatch);
-                        if (ADm >> 31) build_profile5(prof0 + (2 * p + 1) * (4 * 64), rwn[2 * p + 1], Pm.match, Pm.mismatch);
-                    }
-                }
             }
         }
 
