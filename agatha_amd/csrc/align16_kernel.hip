@@ -196,6 +196,15 @@ __device__ __forceinline__ void row_keys4(int& a0, int& a1, int& a2, int& a3, ui
 #undef AGATHA16_KEY
 }
 
+// profile row of query class (bits shift+1..shift of the class word): v_bfe_u32 + v_lshl_add_u32 (laundered so that the
+// compiler does not turn the pair into shift + and + add)
+__device__ __forceinline__ uint2 profile_row(const uint2* __restrict__ p, uint32_t qc, int shift)
+{
+    uint32_t c = __builtin_amdgcn_ubfe(qc, shift, 2);
+    asm("" : "+v"(c));
+    return p[c * 64u];
+}
+
 template <int K>
 __device__ __forceinline__ void block_pair16(uint32_t (&h)[8], uint32_t (&f)[8], uint32_t corner, const uint32_t (&rh)[8],
                                              uint32_t (&e)[8], uint32_t (&oh)[8], int (&A)[15], uint32_t qc_lo, uint32_t qc_hi,
@@ -204,15 +213,15 @@ __device__ __forceinline__ void block_pair16(uint32_t (&h)[8], uint32_t (&f)[8],
                                              int crel_lo, int crel_hi)
 {
     // profile rows are requested while the previous row's cells are being computed
-    uint2 wl = pl[__builtin_amdgcn_ubfe(qc_lo, 28, 2) * 64u], wh = ph[__builtin_amdgcn_ubfe(qc_hi, 28, 2) * 64u];
+    uint2 wl = profile_row(pl, qc_lo, 28), wh = profile_row(ph, qc_hi, 28);
 #pragma unroll
     for (int il = 0; il < 8; il++) {
         // key multiplier of this row: 2^K where the row exists (il < rows), 0 where it does not
         const uint32_t kmul = pk_min_c(pk_sub_sat_c(NRK, dup2((uint32_t)(il << K))), dup2(1u << K));
         row_add_scores(h, il == 0 ? corner : rh[il > 0 ? il - 1 : 0], wl, wh);
         if (il < 7) {
-            wl = pl[__builtin_amdgcn_ubfe(qc_lo, 24 - 4 * il, 2) * 64u];
-            wh = ph[__builtin_amdgcn_ubfe(qc_hi, 24 - 4 * il, 2) * 64u];
+            wl = profile_row(pl, qc_lo, 24 - 4 * il);
+            wh = profile_row(ph, qc_hi, 24 - 4 * il);
         }
         uint32_t ev = e[il];
         // per-cell gap-extension operands: cell diagonal jl - il == 0 / -1 (E) and 0 / +1 (F) may be cut

@@ -163,6 +163,22 @@ void agatha_amd_last_config(int* G, int* S) { if (G) *G = g_lastG; if (S) *S = g
 
 int agatha_amd_last_int16_config(void) { return g_last16; }
 
+int agatha_amd_pair_kinds(void* stream, const void* d_workspace, uint32_t n_alns, uint32_t counts[3])
+{
+    if (!d_workspace || !counts || n_alns == 0) return AGATHA_AMD_EINVAL;
+    const char* ws = (const char*)d_workspace;
+    ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets) + kAlign + round_up(sizeof(agatha::AlignLaunch));
+    uint8_t* h = (uint8_t*)malloc(n_alns);
+    if (!h) return AGATHA_AMD_EINVAL;
+    hipError_t e = hipMemcpyAsync(h, ws, n_alns, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { free(h); return hip_fail(e, "agatha_amd_pair_kinds"); }
+    counts[0] = counts[1] = counts[2] = 0;
+    for (uint32_t k = 0; k < n_alns; k++) if (h[k] < 3) counts[h[k]]++;
+    free(h);
+    return 0;
+}
+
 int agatha_amd_malloc(void** d_ptr, size_t bytes) { if (!d_ptr) return AGATHA_AMD_EINVAL; HIPCHK(hipMalloc(d_ptr, bytes ? bytes : 1)); return 0; }
 int agatha_amd_free(void* d_ptr) { if (d_ptr) HIPCHK(hipFree(d_ptr)); return 0; }
 int agatha_amd_host_alloc(void** h_ptr, size_t bytes) { if (!h_ptr) return AGATHA_AMD_EINVAL; HIPCHK(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault)); return 0; }

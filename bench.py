@@ -24,7 +24,9 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # int32 VALU roof: v_max/v_max3/v_add3/v_cndmask/v_cmp sustain ~15 lanes/clk/SIMD on this chip (4 cycles per wave64
 # instruction; tools/microbench/valu_rate.hip, profiles/r01_v1/valu_issue_rate_microbench.txt) -> 256 CU x 4 SIMD x 16 x 2.4 GHz
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-OPS_PER_CELL = 11                     # algorithmic int32 ops of one DP cell incl. the anti-diagonal maximum
+# algorithmic VALU lane-ops of one DP cell incl. the anti-diagonal maximum: 11 int32 ops per cell in the
+# int32 kernel; 12 packed ops per TWO cells in the packed-int16 kernel (2 score adds, 4 max, 3 sub, 2 key mads, 1 max3)
+OPS_PER_CELL = {"int32": 11.0, "int16": 6.0}
 
 
 def algorithmic_bytes(qlen, tlen):
@@ -188,9 +190,14 @@ def main():
             traffic = float(pm["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
+    kinds = b.pair_kinds(stream)            # how the last step's pairs were routed between the kernels
     kms = [eng.elapsed_ms(e0, e1) for e0, e1 in kev] if a.steps else [float("nan")]
     kernel_ms = float(np.mean(kms))
     G, S = eng.last_config()
+    cfg16 = eng.last_int16_config()         # the packed-int16 kernel takes the plain pairs when scores / band allow it
+    kind = "int16" if cfg16 else "int32"
+    kname = f"agatha::align16_kernel<{cfg16[0]},{cfg16[1] // 2}>" if cfg16 else f"agatha::align_kernel<{G},{S},false>"
+    Gd, Sd = cfg16 if cfg16 else (G, S)
 
     if rank == 0:
         ms_per_step = elapsed / max(a.steps, 1) * 1e3
@@ -204,11 +211,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": kind,
             "data": "synthetic",
             "config": {"workload": f"C1: {a.pairs} synthetic ONT-like pairs per GPU, ~10 kb (8-12 kb), "
                                    f"sub 3% ins 3% del 4%, m2 x4 q4 r2 w751 z400 s3 (BASELINE.json configs[1])",
-                       "pairs_per_gpu": a.pairs, "lanes_per_pair": G, "slots_per_lane": S,
+                       "pairs_per_gpu": a.pairs, "lanes_per_pair": Gd, "slots_per_lane": Sd, "kernel": kname,
+                       "int32_fallback_kernel": f"agatha::align_kernel<{G},{S}>",
+                       "pairs_plain_other_letters_int32_takeover_rank0": list(kinds),
                        "step": "pack + sort + align + D2H results" + (" + RCCL all-gather" if use_dist else "")},
             "pairs_per_s": total_pairs * a.steps / elapsed,
             "kernel_ms": kernel_ms,
@@ -217,13 +226,15 @@ def main():
                          "frac": abytes / kernel_ms / 1e6 / HBM_PEAK_GBS,
                          "traffic": (traffic / kernel_ms / 1e6) if traffic else None,
                          "algorithmic_bytes_per_launch": abytes, "traffic_bytes_per_launch": traffic,
-                         "kernel": f"agatha::align_kernel<{G},{S}>",
+                         "kernel": kname,
                          "note": "integer max/add DP at ~1400 cells per algorithmic byte: the HBM roof is not binding, "
                                  "see roofline_valu (DESIGN.md, SURVEY.md 8(d))"},
-            "roofline_valu": {"bound": "valu-int32", "achieved": cells * OPS_PER_CELL / kernel_ms / 1e9,
-                              "peak": VALU_PEAK_TOPS, "unit": "Tops/s",
-                              "frac": cells * OPS_PER_CELL / kernel_ms / 1e9 / VALU_PEAK_TOPS,
-                              "ops_per_cell": OPS_PER_CELL},
+            "roofline_valu": {"bound": "valu-" + kind, "achieved": cells * OPS_PER_CELL[kind] / kernel_ms / 1e9,
+                              "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
+                              "frac": cells * OPS_PER_CELL[kind] / kernel_ms / 1e9 / VALU_PEAK_TOPS,
+                              "ops_per_cell": OPS_PER_CELL[kind],
+                              "note": "lane-ops the recurrence itself needs per cell x cells/s over the measured VALU issue "
+                                      "rate of the chip; the int16 kernel does two cells per packed lane-op"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(qb, tb, qo, to, ql, tl, dict(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND), W_BAND)

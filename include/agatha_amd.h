@@ -99,6 +99,12 @@ void agatha_amd_last_config(int* lanes_per_pair, int* slots_per_lane);
  * kernels), 0 if it did not.  AGATHA_AMD_NO_INT16=1 in the environment keeps every pair on the int32 kernels. */
 int agatha_amd_last_int16_config(void);
 
+/* Diagnostics: how the last agatha_amd_align() on this workspace routed its n_alns pairs.  counts[0] = plain pairs
+ * (aligned by the packed-int16 kernel when it ran, else by the int32 profile kernel), counts[1] = pairs with letters
+ * outside ACGTN (compare kernel), counts[2] = pairs the int32 profile kernel took over (N in the query, or handed
+ * back by the int16 kernel).  Synchronises the stream. */
+int agatha_amd_pair_kinds(void* stream, const void* d_workspace, uint32_t n_alns, uint32_t counts[3]);
+
 /* Thin device-memory helpers so that non-HIP hosts (ctypes, cgo, JNI) can drive the library without
  * linking the HIP runtime themselves.  Synchronous except the *_async copies. */
 int agatha_amd_malloc(void** d_ptr, size_t bytes);

@@ -1,0 +1,139 @@
+"""GPU parity of the packed-int16 kernel (agatha_amd/csrc/align16_kernel.hip) and of the routing between it, the
+int32 profile kernel and the compare kernel.  Needs a real MI355X: `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from agatha_amd import workload as WL
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import agatha_amd
+    e = agatha_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def _run(eng, qs, ts, p):
+    import agatha_amd
+    qb, qo, ql = WL.make_batch(qs)
+    tb, to, tl = WL.make_batch(ts)
+    got = eng.align_host_batch(qb, tb, qo, to, ql, tl, agatha_amd.Scores.make(**p))
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=8)
+    return got, exp
+
+
+def _same(got, exp):
+    return all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got, exp))
+
+
+@pytest.mark.parametrize("p", [BASE, dict(BASE, w=760), dict(BASE, s=1), dict(BASE, z=-1), dict(BASE, z=0),
+                               dict(m=1, x=4, q=6, r=2, s=2, z=100, w=760), dict(m=16, x=32, q=64, r=16, s=3, z=2000, w=103)],
+                         ids=lambda p: "m%dx%dq%dr%ds%dz%dw%d" % (p["m"], p["x"], p["q"], p["r"], p["s"], p["z"], p["w"]))
+def test_int16_kernel_matches_oracle(eng, p):
+    """Both cut diagonals (w = 751: t0 = -1, w = 760: t0 = 0), slice widths, z-drop on/off/immediate, and a scoring at
+    the edge of the int16 kernel's domain (w = 103 there: the launcher must pick the int32 kernel, t0 = -1 but no
+    int16 configuration for that window)."""
+    qs, ts = WL.cfg_c4(n=160, seed=31 + p["w"], lo=50, hi=14000)
+    got, exp = _run(eng, qs, ts, p)
+    assert _same(got, exp)
+    if p["w"] in (751, 760):
+        assert eng.last_int16_config() == (16, 6)       # the packed kernel really ran
+    else:
+        assert eng.last_int16_config() is None
+
+
+def test_int16_and_int32_kernels_agree(eng):
+    import agatha_amd
+    qs, ts = WL.cfg_c1(n=300, seed=77)
+    qb, qo, ql = WL.make_batch(qs)
+    tb, to, tl = WL.make_batch(ts)
+    sc = agatha_amd.Scores.make(**BASE)
+    a = eng.align_host_batch(qb, tb, qo, to, ql, tl, sc)
+    assert eng.last_int16_config() == (16, 6)
+    os.environ["AGATHA_AMD_NO_INT16"] = "1"
+    try:
+        b = eng.align_host_batch(qb, tb, qo, to, ql, tl, sc)
+        assert eng.last_int16_config() is None
+    finally:
+        del os.environ["AGATHA_AMD_NO_INT16"]
+    assert _same(a, b)
+
+
+def test_rebasing_long_pairs(eng):
+    """Scores far beyond int16 (2 x 60 kb): the representation is rebased ~60 times per pair."""
+    f = lambda rng: int(rng.integers(30000, 60001))
+    qs, ts = WL.make_pairs(5, 24, f, 0.01, 0.01, 0.01)
+    got, exp = _run(eng, qs, ts, BASE)
+    assert _same(got, exp)
+    assert int(np.max(exp[0])) > 40000
+
+
+def test_pairs_the_int16_kernel_hands_back(eng):
+    """z-drop switched off on unrelated sequences: the scores sink until the int16 kernel abandons the pair (bail-out)
+    and the int32 kernel redoes it; pairs whose band leaves the matrix through its side (lengths differing by more than
+    the band) produce empty anti-diagonals."""
+    rng = np.random.default_rng(9)
+    qs = [WL.random_seq(rng, 9000).tobytes() for _ in range(12)]
+    ts = [WL.random_seq(rng, 9000).tobytes() for _ in range(12)]
+    base = WL.random_seq(rng, 6000)
+    for extra in (800, 1600, 3000):                      # |Q - R| > band
+        qs.append(base.tobytes()); ts.append(np.concatenate([base, WL.random_seq(rng, extra)]).tobytes())
+        qs.append(np.concatenate([base, WL.random_seq(rng, extra)]).tobytes()); ts.append(base.tobytes())
+    for p in (dict(BASE, z=-1), BASE, dict(BASE, w=760, z=30000)):
+        got, exp = _run(eng, qs, ts, p)
+        assert _same(got, exp)
+    # with z-drop off the twelve unrelated pairs must really have been handed back
+    import agatha_amd
+    qb, qo, ql = WL.make_batch(qs)
+    tb, to, tl = WL.make_batch(ts)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**dict(BASE, z=-1)))
+        plain, other, takeover = b.pair_kinds()
+    finally:
+        b.free()
+    assert other == 0 and takeover >= 12 and plain + takeover == len(qs)
+
+
+def test_n_in_query_and_other_letters_are_routed(eng):
+    """N in the query has no row in the int16 kernel's score profile (int32 profile kernel takes the pair); letters
+    outside ACGTN go to the compare kernel; N in the reference stays on the int16 kernel."""
+    rng = np.random.default_rng(4)
+    qs, ts = [], []
+    for k in range(30):
+        ref = WL.random_seq(rng, int(rng.integers(500, 6000)))
+        rd = WL.mutate(rng, ref, 0.03, 0.03, 0.04)
+        ref, rd = ref.copy(), rd.copy()
+        if k % 3 == 0:
+            ref[rng.random(ref.size) < 0.02] = ord("N")
+        if k % 3 == 1:
+            rd[rng.random(rd.size) < 0.02] = ord("N")
+        if k % 5 == 4:
+            rd[rng.integers(0, rd.size)] = ord("R")
+        qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    got, exp = _run(eng, qs, ts, BASE)
+    assert _same(got, exp)
+
+
+def test_ragged_lengths_around_block_edges(eng):
+    """Every query length modulo 8 (rows that do not exist in the last row block) against every target length modulo 8
+    (padded reference columns)."""
+    rng = np.random.default_rng(12)
+    qs, ts = [], []
+    for dq in range(8):
+        for dt in range(8):
+            ref = WL.random_seq(rng, 1600 + dq)
+            rd = WL.mutate(rng, ref, 0.02, 0.02, 0.02)
+            rd = rd[:max(1, (rd.size // 8) * 8 - 8 + dt)]
+            qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    for p in (BASE, dict(BASE, w=760, s=2)):
+        got, exp = _run(eng, qs, ts, p)
+        assert _same(got, exp)

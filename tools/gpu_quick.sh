@@ -8,13 +8,13 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_V
 tail -2 gpurun_out/pytest_gpu_$TAG.log
 python3 - <<PY
 import json,csv,glob,collections
-b=json.load(open("gpurun_out/bench_$TAG.json")); print("GCUPS",round(b["value"],1),"kernel_ms",round(b["kernel_ms"],2),"cfg",b["config"]["lanes_per_pair"],b["config"]["slots_per_lane"])
+b=json.load(open("gpurun_out/bench_$TAG.json")); print("GCUPS",round(b["value"],1),"kernel_ms",round(b["kernel_ms"],2),"kernel",b["config"]["kernel"])
 agg=collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_$TAG/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "align_kernel" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if b["config"]["kernel"].split("::")[1].split("<")[0] + "<" in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m={k:sum(v)/len(v) for k,v in agg.items()}
-cells=1.437e11
+cells=1.367e11
 print({k:"%.3e"%v for k,v in m.items()})
 if "SQ_INSTS_VALU" in m: print("VALU lane-ops/cell %.2f"%(m["SQ_INSTS_VALU"]*64/cells), "SALU/VALU %.2f"%(m["SQ_INSTS_SALU"]/m["SQ_INSTS_VALU"]))
 PY
