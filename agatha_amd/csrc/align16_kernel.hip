@@ -18,8 +18,8 @@
 //     the key computation (v_mad_u32_u16).
 //   * a pair whose anti-diagonal maximum comes too close to the zone borders (an in-band cell could leave its zone, or
 //     the exact value of -infinity could start to matter) is abandoned and flagged for the int32 kernel.
-// The launcher only uses this kernel when the band's cut diagonal is t0 = w - 8*ceil(w/8) in {0, -1} (then every
-// boundary block is a regular upper or lower edge block) and the scores pass agatha16_scores_ok().
+// The kernel is compiled per cut diagonal T0 = w - 8*ceil(w/8) (0..-7), so which cells carry a cut operand is known at
+// compile time; the launcher uses it when the scores pass agatha16_scores_ok() and a (G, P) exists for the window.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
@@ -205,11 +205,11 @@ __device__ __forceinline__ uint2 profile_row(const uint2* __restrict__ p, uint32
     return p[c * 64u];
 }
 
-template <int K>
+template <int K, int T0>
 __device__ __forceinline__ void block_pair16(uint32_t (&h)[8], uint32_t (&f)[8], uint32_t corner, const uint32_t (&rh)[8],
                                              uint32_t (&e)[8], uint32_t (&oh)[8], int (&A)[15], uint32_t qc_lo, uint32_t qc_hi,
                                              const uint2* __restrict__ pl, const uint2* __restrict__ ph, uint32_t gapo2,
-                                             uint32_t ge2, uint32_t gee0, uint32_t geem1, uint32_t gef0, uint32_t gef1, uint32_t NRK,
+                                             uint32_t ge2, uint32_t gcu, uint32_t gcu2, uint32_t gcl, uint32_t gcl2, uint32_t NRK,
                                              int crel_lo, int crel_hi)
 {
     // profile rows are requested while the previous row's cells are being computed
@@ -224,9 +224,10 @@ __device__ __forceinline__ void block_pair16(uint32_t (&h)[8], uint32_t (&f)[8],
             wh = profile_row(ph, qc_hi, 24 - 4 * il);
         }
         uint32_t ev = e[il];
-        // per-cell gap-extension operands: cell diagonal jl - il == 0 / -1 (E) and 0 / +1 (F) may be cut
-#define GE_E(jl) ((jl) - il == 0 ? gee0 : (jl) - il == -1 ? geem1 : ge2)
-#define GE_F(jl) ((jl) - il == 0 ? gef0 : (jl) - il == 1 ? gef1 : ge2)
+        // per-cell gap-extension operands: E is cut on cell diagonal jl - il == T0 (upper edge blocks) or T0 + 8 (the
+        // block next to the corner of the band), F on -T0 or -(T0 + 8) (lower edge blocks); everywhere else plain ge
+#define GE_E(jl) ((jl) - il == T0 ? gcu : (jl) - il == T0 + 8 ? gcu2 : ge2)
+#define GE_F(jl) ((jl) - il == -T0 ? gcl : (jl) - il == -(T0 + 8) ? gcl2 : ge2)
         row_cells4(h[0], h[1], h[2], h[3], f[0], f[1], f[2], f[3], ev, gapo2, GE_F(0), GE_F(1), GE_F(2), GE_F(3), GE_E(0), GE_E(1), GE_E(2), GE_E(3));
         row_cells4(h[4], h[5], h[6], h[7], f[4], f[5], f[6], f[7], ev, gapo2, GE_F(4), GE_F(5), GE_F(6), GE_F(7), GE_E(4), GE_E(5), GE_E(6), GE_E(7));
 #undef GE_E
@@ -246,10 +247,12 @@ __device__ __forceinline__ uint32_t lt_mask(uint32_t a, uint32_t b, uint32_t f15
 // a == b
 __device__ __forceinline__ uint32_t eq_mask(uint32_t a, uint32_t b, uint32_t one2) { return pk_sub_c(pk_min_c(a ^ b, one2), one2); }
 
-template <int G, int P>
+template <int G, int P, int T0>
 __global__ void __launch_bounds__(256, 2)
 align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
 {
+    static_assert(T0 <= 0 && T0 >= -7, "T0 = w - 8 * ceil(w / 8)");
+    constexpr bool CORNER_BLOCKS = (T0 + 8 < 7);   // blocks (0, W-1) and (pql-1, pql-W) are cut as well
     constexpr int S = 2 * P, GS = G * S;
     constexpr int K = KeyBits<GS>::value;
     constexpr int KMASK = (1 << K) - 1;
@@ -270,7 +273,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
     const int gapo = Pm.gap_open, ge = Pm.gap_extend, gapoe = gapo + ge;
     const int sw = Pm.slice_width, z = Pm.z_threshold, w = Pm.band_width;
     const int W = (w + 7) >> 3;
-    const int t0 = w - 8 * W;                      // 0 or -1 here (launcher); the cut diagonal of edge blocks
+    constexpr int t0 = T0;                         // = w - 8 * W (launcher): the cut diagonal of edge blocks
     int spread;                                    // how far below an anti-diagonal maximum an in-band cell can be
     {
         int per = 2 * ge; if (Pm.mismatch > per) per = Pm.mismatch; if (per < 1) per = 1;
@@ -282,7 +285,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
     const uint32_t W2 = dup2((uint32_t)W), NOTAG = 0xFFFEFFFEu;
     const ProfileLut plut = make_profile_lut(Pm.match, Pm.mismatch);
     // initial state of a column block beyond the first band width (init_half with r > W): constants per column
-    const uint32_t HINIT = (t0 < 0) ? OUT2 : OUT2, H7INIT = NEG2;     // h[m], m < 7: the cell it is the diagonal of, (0, m+1), is outside for t0 <= 0
+    const uint32_t HINIT = OUT2, H7INIT = NEG2;     // h[m], m < 7: the cell it is the diagonal of, (0, m+1), is outside for t0 <= 0
     const uint32_t F0INIT = (0 > t0) ? OUT2 : NEG2, FINIT = OUT2, CINIT = (0 > t0) ? OUT2 : NEG2;
 
     // ---- per-pair state (uniform inside a group) ----
@@ -397,9 +400,25 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
             const uint32_t ACTm = ~(lt_mask(q2, cs2, F15) | lt_mask(ce2, q2, F15) | lt_mask(rc, SS2, F15) | lt_mask(SE2, rc, F15)) & RUNm;
             {
                 const int ra = (int)(rc & 0xffffu), rb = (int)(rc >> 16);
-                // regular edge blocks: q == r - W (upper, cut on cell diagonal t0), q == r + W (lower, cut on -t0);
-                // every other block is uncut when t0 is 0 or -1
+                // edge blocks: q == r - W (upper, E cut on cell diagonal T0), q == r + W (lower, F cut on -T0); for T0 < -1
+                // also the two blocks next to the corners of the band: (0, W-1) (E cut on T0 + 8) and (pql-1, pql-W)
+                // (F cut on -(T0 + 8)).  Every other block is uncut.
                 const uint32_t UPm = eq_mask(pk_add(q2, W2), rc, ONE2) & ACTm, LOm = eq_mask(q2, pk_add(rc, W2), ONE2) & ACTm;
+                uint32_t UP2m = 0u, LO2m = 0u;
+                if (CORNER_BLOCKS) {
+                    UP2m = eq_mask(q2, 0u, ONE2) & eq_mask(rc, dup2((uint32_t)(W - 1)), ONE2) & ACTm;
+                    LO2m = eq_mask(q2, PQL1, ONE2) & eq_mask(pk_add(q2, ONE2), pk_add(rc, W2), ONE2) & ACTm;
+                }
+                {
+                    // safety net: a boundary block with a cut that is none of the kinds above must not be computed here
+                    const uint32_t bnd = (eq_mask(q2, cs2, ONE2) | eq_mask(q2, ce2, ONE2)) & ACTm & ~(UPm | LOm | UP2m | LO2m);
+                    if (__builtin_expect(bnd != 0u, 0)) {
+                        const int qa_ = i - ra, qb_ = i - rb;
+                        const bool bada = (bnd & 1u) && (w + 8 * qa_ - 8 * ra < 7 || w - 8 * qa_ + 8 * ra < 7);
+                        const bool badb = (bnd >> 31) && (w + 8 * qb_ - 8 * rb < 7 || w - 8 * qb_ + 8 * rb < 7);
+                        if (bada || badb) bail = true;
+                    }
+                }
                 // slots that leave their column block after this step (q + 1 > ce) move on to column r + G*S: the reference
                 // word of the new column is requested now and used after the block
                 const uint32_t ADm = alive ? ~lt_mask(q2, ce2, F15) : 0u;
@@ -411,7 +430,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
                     // pass start: padded ref columns fall back to -infinity (agatha_kernel.h:207-215); where the value
                     // would enter an out-of-band cell of an upper edge block it is R_OUT as in init_half
                     const bool acta = (ACTm & 1u) != 0u, actb = (ACTm >> 31) != 0u;
-                    const int tua = (UPm & 1u) ? t0 : 1000, tub = (UPm >> 31) ? t0 : 1000;
+                    const int tua = (UPm & 1u) ? t0 : (UP2m & 1u) ? t0 + 8 : 1000, tub = (UPm >> 31) ? t0 : (UP2m >> 31) ? t0 + 8 : 1000;
 #pragma unroll
                     for (int m = 0; m < 8; m++) {
                         const bool pa = acta && ra == prl - 1 && 8 * ra + m >= R, pb = actb && rb == prl - 1 && 8 * rb + m >= R;
@@ -443,8 +462,8 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
                     // (agatha_kernel.h:126-131); general per-lane form of the entry rules
                     const bool oka = (okm & 1u) != 0u, okb = (okm >> 31) != 0u;
                     const int qa = i - ra, qb = i - rb;
-                    const int tua = (UPm & 1u) ? t0 : 1000, tub = (UPm >> 31) ? t0 : 1000;
-                    const int tla = (LOm & 1u) ? t0 : 1000, tlb = (LOm >> 31) ? t0 : 1000;
+                    const int tua = (UPm & 1u) ? t0 : (UP2m & 1u) ? t0 + 8 : 1000, tub = (UPm >> 31) ? t0 : (UP2m >> 31) ? t0 + 8 : 1000;
+                    const int tla = (LOm & 1u) ? t0 : (LO2m & 1u) ? t0 + 8 : 1000, tlb = (LOm >> 31) ? t0 : (LO2m >> 31) ? t0 + 8 : 1000;
 #pragma unroll
                     for (int il = 0; il < 8; il++) {
                         const int rowa = 8 * qa + il, rowb = 8 * qb + il;
@@ -464,35 +483,52 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
                     // lower edge blocks: every cell of column 0 below the cut is outside the band, so the missing left
                     // input is R_OUT there (for t0 = 0 cell (0, 0) is inside); everywhere else it is -infinity
                     const uint32_t dflt = bfi(LOm, OUT2, NEG2);
-                    const uint32_t dflt_e0 = (t0 == 0) ? NEG2 : dflt;
+                    const uint32_t dflt_e0 = (t0 == 0) ? NEG2 : dflt;      // for T0 = 0 cell (0, 0) of a lower edge block is inside
 #pragma unroll
                     for (int il = 0; il < 8; il++) {
                         rh[il] = bfi(okm, XH[p][il], il < 7 ? dflt : NEG2);
                         e[il] = bfi(okm, xin[il], il == 0 ? dflt_e0 : dflt);
                     }
-                    // upper edge blocks: cell (0, 0) is outside when t0 = -1
-                    if (t0 < 0) e[0] = bfi(UPm, OUT2, e[0]);
+                    // upper edge blocks: cells (il, 0) with -il > T0 are outside: their E, and the diagonal of the next row
+#pragma unroll
+                    for (int il = 0; il < 8; il++) {
+                        if (il < -t0) e[il] = bfi(UPm, OUT2, e[il]);
+                        if (il >= 1 && il < -t0) rh[il - 1] = bfi(UPm, OUT2, rh[il - 1]);
+                    }
+                    // the block next to the lower corner of the band has a left neighbour, but its cells (il, 0) with
+                    // il > T0 + 8 are outside all the same
+                    if (CORNER_BLOCKS) {
+#pragma unroll
+                        for (int il = 1; il < 8; il++) {
+                            if (il > t0 + 8) { e[il] = bfi(LO2m, OUT2, e[il]); rh[il - 1] = bfi(LO2m, OUT2, rh[il - 1]); }
+                        }
+                    }
                 }
                 uint32_t corner_in = CORNER[p];
-                if (t0 < 0) {
-                    corner_in = bfi(UPm | LOm, OUT2, corner_in);
-                    F[p][0] = bfi(LOm, OUT2, F[p][0]);       // lower edge blocks: cell (0, 0) is outside when t0 = -1
+                if (t0 < 0) corner_in = bfi(UPm | LOm, OUT2, corner_in);
+                // lower edge blocks: cells (0, jl) with -jl > T0 are outside: their F, and the diagonal of the next column
+#pragma unroll
+                for (int jl = 0; jl < 8; jl++) {
+                    if (jl < -t0) F[p][jl] = bfi(LOm, OUT2, F[p][jl]);
+                    if (jl >= 1 && jl < -t0) H[p][jl - 1] = bfi(LOm, OUT2, H[p][jl - 1]);
                 }
 
                 // ---- what E and F lose per step on the cut diagonals ----
                 const uint32_t gcu = bfi(UPm, CUT2, GE2), gcl = bfi(LOm, CUT2, GE2);
-                const uint32_t gee0 = (t0 == 0) ? gcu : GE2, geem1 = (t0 == -1) ? gcu : GE2;
-                const uint32_t gef0 = (t0 == 0) ? gcl : GE2, gef1 = (t0 == -1) ? gcl : GE2;
+                const uint32_t gcu2 = CORNER_BLOCKS ? bfi(UP2m, CUT2, GE2) : GE2, gcl2 = CORNER_BLOCKS ? bfi(LO2m, CUT2, GE2) : GE2;
                 // rows that exist: 8, fewer in the last row block, 0 for an inactive half
                 const uint32_t NR = bfi(eq_mask(q2, PQL1, ONE2), NRLAST, 0x00080008u) & ACTm;
 
-                block_pair16<K>(H[p], F[p], corner_in, rh, e, XH[p], A, class_word(qcls[2 * p]), class_word(qcls[2 * p + 1]), prof0 + (2 * p) * (4 * 64),
-                                prof0 + (2 * p + 1) * (4 * 64), GAPO2, GE2, gee0, geem1, gef0, gef1, pk_shl_c(NR, K2), 8 * ra - cb, 8 * rb - cb);
-                // lower edge blocks, t0 = -1: row 7's last cell is below the band; it hands on what the reference's skipped
-                // cells leave in its registers: H of row 6 at column 7, and the incoming E (-infinity)
-                if (t0 < 0) {
-                    XH[p][7] = bfi(LOm, XH[p][6], XH[p][7]);
-                    e[7] = bfi(LOm, NEG2, e[7]);
+                block_pair16<K, T0>(H[p], F[p], corner_in, rh, e, XH[p], A, class_word(qcls[2 * p]), class_word(qcls[2 * p + 1]), prof0 + (2 * p) * (4 * 64),
+                                    prof0 + (2 * p + 1) * (4 * 64), GAPO2, GE2, gcu, gcu2, gcl, gcl2, pk_shl_c(NR, K2), 8 * ra - cb, 8 * rb - cb);
+                // lower edge blocks: the rows il > 7 + T0 end below the band; they hand on what the reference's skipped cells
+                // leave in its registers: H of row 7 + T0 at column 7, and the incoming E (-infinity)
+#pragma unroll
+                for (int il = 1; il < 8; il++) {
+                    if (il > 7 + t0) {
+                        XH[p][il] = bfi(LOm, XH[p][7 + t0], XH[p][il]);
+                        e[il] = bfi(LOm, NEG2, e[il]);
+                    }
                 }
                 {
                     uint16_t* dst_lo = xe_wave + lane + (2 * p) * (9 * 64);
@@ -554,6 +590,12 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
         }
 
         __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_expect(__any(bail), 0)) {     // the decision belongs to the whole group
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(bail);
+            const unsigned long long gm = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << gbase);
+            bail = (bm & gm) != 0ull;
+        }
+
         // ---- hand-off: slot s feeds slot s + 1 (half swap inside a register pair, or the next register pair);
         //      the last slot feeds slot 0 of the next lane ----
         {
@@ -581,7 +623,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
         for (int x = 1; x < 8; x++) { lo8 = imin(lo8, vred[x]); hi8 = imax(hi8, vred[x]); }
         // Fast path (wave-uniform): every anti-diagonal of this step has an in-band maximum well inside its zone, inside
         // the pair, and within z of the running maximum, so neither z-drop nor the bail-out can fire.
-        bool calm = !final_step && (8 * i + 7 < lim);
+        bool calm = !final_step && (8 * i + 7 < lim) && !bail;
         {
             const int lo_rep = lo8 >> K, lo_abs = lo_rep - r16::BIAS + base, hi_abs = (hi8 >> K) - r16::BIAS + base;
             calm = calm && lo_rep >= bail_rep && lo_abs >= NEG_INF2 + spread && (z < 0 || imax(best, hi_abs) - lo_abs <= z);
@@ -680,7 +722,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-template <int G, int P>
+template <int G, int P, int T0>
 static hipError_t launch_align16_t(const AlignLaunch& L, hipStream_t st)
 {
     const int groups_per_block = (256 / 64) * (64 / G);
@@ -689,49 +731,50 @@ static hipError_t launch_align16_t(const AlignLaunch& L, hipStream_t st)
     if (L.max_blocks_override > 0) max_blocks = L.max_blocks_override;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((align16_kernel<G, P>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
+    hipLaunchKernelGGL((align16_kernel<G, P, T0>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
     return hipGetLastError();
 }
 
-struct Cfg16 { int G, P; hipError_t (*fn)(const AlignLaunch&, hipStream_t); };
-static const Cfg16 kCfgs16[] = {       // ascending G * 2P
-    {16, 3, launch_align16_t<16, 3>},
+typedef hipError_t (*launch16_fn)(const AlignLaunch&, hipStream_t);
+struct Cfg16 { int G, P; launch16_fn fn[8]; };        // fn[-T0]
+#define AGATHA16_CFG(G, P) {G, P, {launch_align16_t<G, P, 0>, launch_align16_t<G, P, -1>, launch_align16_t<G, P, -2>, launch_align16_t<G, P, -3>, \
+                                   launch_align16_t<G, P, -4>, launch_align16_t<G, P, -5>, launch_align16_t<G, P, -6>, launch_align16_t<G, P, -7>}}
+static const Cfg16 kCfgs16[] = {       // ascending G * 2P: windows of 32, 64, 96, 128, 192 blocks
+    AGATHA16_CFG(16, 1), AGATHA16_CFG(16, 2), AGATHA16_CFG(16, 3), AGATHA16_CFG(32, 2), AGATHA16_CFG(32, 3),
 };
 
 bool agatha16_scores_ok(const AlignParams& p)
 {
     if (p.band_width < 16) return false;
-    const int W = (p.band_width + 7) / 8, t0 = p.band_width - 8 * W;
-    if (t0 < -1) return false;
     if (p.match < 0 || p.match > 16 || p.mismatch < 0 || p.mismatch > 32) return false;
     if (p.gap_open < 0 || p.gap_open > 64 || p.gap_extend < 0 || p.gap_extend > 16) return false;
     int per = 2 * p.gap_extend; if (p.mismatch > per) per = p.mismatch; if (per < 1) per = 1;
     const int spread = p.gap_open + p.gap_extend + per * (p.band_width + 16) + 64;
-    return spread <= 6000;
+    return spread <= 7000;
 }
 
-// true if a packed-int16 configuration exists for this window; launches it (kind-0 pairs only)
+// the smallest packed-int16 configuration that holds the window, unless it would leave most of its slots idle
+static const Cfg16* pick16(const AlignParams& p, int window_blocks)
+{
+    if (!agatha16_scores_ok(p)) return nullptr;
+    for (const Cfg16& c : kCfgs16)
+        if (c.G * 2 * c.P >= window_blocks) return (c.G * 2 * c.P <= 2 * window_blocks + 32) ? &c : nullptr;
+    return nullptr;
+}
+
+bool align16_available(const AlignParams& p, int window_blocks) { return pick16(p, window_blocks) != nullptr; }
+
+// launches the packed-int16 kernel (kind-0 pairs only) if a configuration exists for this window
 bool launch_align16(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st, hipError_t* err)
 {
     *err = hipSuccess;
-    if (!agatha16_scores_ok(L.p)) return false;
-    for (const Cfg16& c : kCfgs16) {
-        if (c.G * 2 * c.P >= window_blocks && c.G * 2 * c.P <= 2 * window_blocks + 32) {
-            if (G_out) *G_out = c.G;
-            if (S_out) *S_out = 2 * c.P;
-            *err = c.fn(L, st);
-            return true;
-        }
-    }
-    return false;
-}
-
-bool align16_available(const AlignParams& p, int window_blocks)
-{
-    if (!agatha16_scores_ok(p)) return false;
-    for (const Cfg16& c : kCfgs16)
-        if (c.G * 2 * c.P >= window_blocks && c.G * 2 * c.P <= 2 * window_blocks + 32) return true;
-    return false;
+    const Cfg16* c = pick16(L.p, window_blocks);
+    if (!c) return false;
+    const int W = (L.p.band_width + 7) / 8, t0 = L.p.band_width - 8 * W;
+    if (G_out) *G_out = c->G;
+    if (S_out) *S_out = 2 * c->P;
+    *err = c->fn[-t0](L, st);
+    return true;
 }
 
 }  // namespace agatha

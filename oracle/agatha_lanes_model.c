@@ -264,7 +264,7 @@ int agatha_lanes16_eligible(const lm_params_t *pr)
     if (pr->band_width < 16) return 0;
     if (pr->match < 0 || pr->match > 16 || pr->mismatch < 0 || pr->mismatch > 32) return 0;
     if (pr->gap_open < 0 || pr->gap_open > 64 || pr->gap_extend < 0 || pr->gap_extend > 16) return 0;
-    if (agatha_lanes16_spread(pr) > 6000) return 0;
+    if (agatha_lanes16_spread(pr) > 7000) return 0;
     return 1;
 }
 

@@ -34,20 +34,49 @@ def _same(got, exp):
     return all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got, exp))
 
 
+def _expected_int16_config(p):
+    """(lanes per pair, slots per lane) the launcher must choose, or None (agatha_amd/csrc/align16_kernel.hip: pick16)."""
+    W = (p["w"] + 7) // 8
+    per = max(2 * p["r"], p["x"], 1)
+    if p["w"] < 16 or p["q"] + p["r"] + per * (p["w"] + 16) + 64 > 7000:
+        return None
+    for G, S in ((16, 2), (16, 4), (16, 6), (32, 4), (32, 6)):
+        if G * S >= W + 1:
+            return (G, S) if G * S <= 2 * (W + 1) + 32 else None
+    return None
+
+
 @pytest.mark.parametrize("p", [BASE, dict(BASE, w=760), dict(BASE, s=1), dict(BASE, z=-1), dict(BASE, z=0),
-                               dict(m=1, x=4, q=6, r=2, s=2, z=100, w=760), dict(m=16, x=32, q=64, r=16, s=3, z=2000, w=103)],
+                               dict(m=1, x=4, q=6, r=2, s=2, z=100, w=760), dict(m=16, x=32, q=64, r=16, s=3, z=2000, w=103),
+                               dict(BASE, w=500), dict(BASE, w=100, s=2), dict(BASE, w=1000), dict(BASE, w=1400, z=1000),
+                               dict(BASE, w=1500), dict(BASE, w=2000), dict(BASE, w=15)],
                          ids=lambda p: "m%dx%dq%dr%ds%dz%dw%d" % (p["m"], p["x"], p["q"], p["r"], p["s"], p["z"], p["w"]))
 def test_int16_kernel_matches_oracle(eng, p):
-    """Both cut diagonals (w = 751: t0 = -1, w = 760: t0 = 0), slice widths, z-drop on/off/immediate, and a scoring at
-    the edge of the int16 kernel's domain (w = 103 there: the launcher must pick the int32 kernel, t0 = -1 but no
-    int16 configuration for that window)."""
-    qs, ts = WL.cfg_c4(n=160, seed=31 + p["w"], lo=50, hi=14000)
+    """Cut diagonals, windows (16x2 ... 32x6 slots), slice widths, z-drop on/off/immediate, a scoring at the edge of the
+    int16 kernel's domain, and bands the launcher must leave to the int32 kernel (w = 1500 / 2000: in-band values can
+    spread too far for the int16 zones; w = 15: too narrow)."""
+    hi = 14000 if p["w"] <= 1000 else 30000
+    qs, ts = WL.cfg_c4(n=160 if p["w"] <= 1000 else 96, seed=31 + p["w"], lo=50, hi=hi)
     got, exp = _run(eng, qs, ts, p)
     assert _same(got, exp)
-    if p["w"] in (751, 760):
-        assert eng.last_int16_config() == (16, 6)       # the packed kernel really ran
-    else:
-        assert eng.last_int16_config() is None
+    assert eng.last_int16_config() == _expected_int16_config(p)
+
+
+@pytest.mark.parametrize("w", list(range(745, 753)) + [97, 250, 505])
+def test_every_cut_diagonal(eng, w):
+    """w mod 8 decides which cell diagonal of an edge block is cut (one compiled kernel per value), and for w mod 8 in
+    1..6 the two blocks next to the corners of the band are cut as well."""
+    p = dict(BASE, w=w, s=int(1 + w % 3))
+    qs, ts = WL.cfg_c4(n=128, seed=1000 + w, lo=30, hi=12000)
+    rng = np.random.default_rng(w)
+    for L in (7, 8, 9, 8 * ((w + 7) // 8) - 1, 8 * ((w + 7) // 8) + 1, w, w + 1, 2 * w, 2 * w + 9):     # matrices around the band's corners
+        a = WL.random_seq(rng, L)
+        qs.append(a.tobytes()); ts.append(WL.mutate(rng, a, 0.02, 0.02, 0.02).tobytes() or b"A")
+        qs.append(a.tobytes()); ts.append(np.concatenate([a, WL.random_seq(rng, w + 40)]).tobytes())
+        qs.append(np.concatenate([a, WL.random_seq(rng, w + 40)]).tobytes()); ts.append(a.tobytes())
+    got, exp = _run(eng, qs, ts, p)
+    assert _same(got, exp)
+    assert eng.last_int16_config() == _expected_int16_config(p)
 
 
 def test_int16_and_int32_kernels_agree(eng):
