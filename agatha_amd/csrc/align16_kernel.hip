@@ -764,6 +764,14 @@ static const Cfg16* pick16(const AlignParams& p, int window_blocks)
 
 bool align16_available(const AlignParams& p, int window_blocks) { return pick16(p, window_blocks) != nullptr; }
 
+// lane groups of the kernel's persistent grid (2 workgroups of 4 waves per CU): with fewer pairs than that the batch is
+// latency-bound and the int32 kernel's shorter steps win
+int align16_group_capacity(const AlignParams& p, int window_blocks, int num_cus)
+{
+    const Cfg16* c = pick16(p, window_blocks);
+    return c ? num_cus * 8 * (64 / c->G) : 0;
+}
+
 // launches the packed-int16 kernel (kind-0 pairs only) if a configuration exists for this window
 bool launch_align16(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st, hipError_t* err)
 {

@@ -273,6 +273,9 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
             if (__all(exhausted)) break;
             continue;                              // every group drew a pair of the other kind: draw again
         }
+        // the steps run in an inner loop of their own, left only when a group wants a new pair (with the queue code in
+        // the same loop the register allocator spills)
+        do {
 
         // ------------------------------------------------------------------ one step
         // column base of the packed maxima: one block left of the lowest active column block
@@ -432,6 +435,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
             if (k == 0) { La->score[pair] = best; La->qend[pair] = best_q; La->tend[pair] = best_t; }   // :359-363
             alive = false;
         }
+        } while (!__any(!alive && !exhausted));
     }
 }
 

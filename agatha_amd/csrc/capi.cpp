@@ -139,9 +139,12 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     HIPCHK(agatha::launch_exotic(L, st));
     { const char* e = getenv("AGATHA_AMD_MAX_BLOCKS"); L.max_blocks_override = e ? atoi(e) : 0; }
     // the packed-int16 kernel takes the plain pairs first when the scores and the band allow it
-    // (AGATHA_AMD_NO_INT16=1 keeps everything on the int32 kernels: A/B runs, debugging)
+    // and the batch has enough pairs to fill its lane groups (AGATHA_AMD_NO_INT16=1 keeps everything on the int32
+    // kernels, AGATHA_AMD_FORCE_INT16=1 uses the int16 kernel for small batches too: A/B runs, tests)
     { const char* e = getenv("AGATHA_AMD_NO_INT16");
-      L.use16 = (!L.force_cmp && !(e && atoi(e)) && agatha::align16_available(L.p, (int)window)) ? 1 : 0; }
+      const char* f = getenv("AGATHA_AMD_FORCE_INT16");
+      const int cap = agatha::align16_group_capacity(L.p, (int)window, L.num_cus);
+      L.use16 = (!L.force_cmp && !(e && atoi(e)) && cap > 0 && ((f && atoi(f)) || (long)n_alns >= (long)cap)) ? 1 : 0; }
     L.self_dev = rec;
     HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record + queue head reset, stream-ordered
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));

@@ -28,6 +28,7 @@ hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int
 int max_window_blocks();
 // packed-int16 kernel (align16_kernel.hip): usable for these scores / this window?  launch (kind-0 pairs only)
 bool align16_available(const AlignParams& p, int window_blocks);
+int align16_group_capacity(const AlignParams& p, int window_blocks, int num_cus);
 bool launch_align16(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st, hipError_t* err);
 int key_bits_for_window(int window_blocks);
 // writes L into *rec on the device (by-value kernel argument: no host-memory lifetime to care about) and zeroes *L.queue

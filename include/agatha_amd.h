@@ -96,7 +96,9 @@ void agatha_amd_last_config(int* lanes_per_pair, int* slots_per_lane);
 
 /* (lanes_per_pair << 8) | slots_per_lane of the packed-int16 kernel if the last agatha_amd_align() of this thread
  * launched it (plain-letter pairs run there first; pairs it hands back and pairs with other letters run on the int32
- * kernels), 0 if it did not.  AGATHA_AMD_NO_INT16=1 in the environment keeps every pair on the int32 kernels. */
+ * kernels), 0 if it did not: scores or band outside its domain, or fewer pairs than its persistent grid has lane groups
+ * (a latency-bound batch runs faster on the int32 kernel).  Environment: AGATHA_AMD_NO_INT16=1 keeps every pair on the
+ * int32 kernels, AGATHA_AMD_FORCE_INT16=1 uses the int16 kernel for small batches as well. */
 int agatha_amd_last_int16_config(void);
 
 /* Diagnostics: how the last agatha_amd_align() on this workspace routed its n_alns pairs.  counts[0] = plain pairs

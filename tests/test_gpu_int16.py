@@ -16,9 +16,24 @@ BASE = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
 @pytest.fixture(scope="module")
 def eng():
     import agatha_amd
+    os.environ["AGATHA_AMD_FORCE_INT16"] = "1"      # the launcher leaves small batches to the int32 kernel otherwise
     e = agatha_amd.Engine(0)
     yield e
     e.close()
+    del os.environ["AGATHA_AMD_FORCE_INT16"]
+
+
+def test_small_batches_stay_on_the_int32_kernel(eng):
+    import agatha_amd
+    qs, ts = WL.cfg_c1(n=64, seed=3)
+    qb, qo, ql = WL.make_batch(qs)
+    tb, to, tl = WL.make_batch(ts)
+    del os.environ["AGATHA_AMD_FORCE_INT16"]
+    try:
+        eng.align_host_batch(qb, tb, qo, to, ql, tl, agatha_amd.Scores.make(**BASE))
+        assert eng.last_int16_config() is None
+    finally:
+        os.environ["AGATHA_AMD_FORCE_INT16"] = "1"
 
 
 def _run(eng, qs, ts, p):

@@ -41,7 +41,8 @@ for name, gen, p in cfgs:
     b.download(); eng.synchronize()
     best = min(ms)
     out[name] = dict(pairs=len(ql), nominal_cells=cells, ms=best, gcups_nominal=cells / best / 1e6,
-                     pairs_per_s=len(ql) / best * 1e3, cfg=eng.last_config(), gen_s=round(time.time() - t0, 1))
+                     pairs_per_s=len(ql) / best * 1e3, cfg=eng.last_config(), int16_cfg=eng.last_int16_config(),
+                     kinds=b.pair_kinds(), gen_s=round(time.time() - t0, 1))
     print(name, out[name], flush=True)
     b.free()
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)

@@ -1,5 +1,6 @@
 """Developer tool (GPU box): packed-int16 kernel vs oracle on a few workloads, with timing.  Run under `timeout`."""
 import os, sys, time
+os.environ.setdefault("AGATHA_AMD_FORCE_INT16", "1")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from agatha_amd import engine as E
