@@ -249,8 +249,9 @@ __device__ __forceinline__ uint32_t eq_mask(uint32_t a, uint32_t b, uint32_t one
 
 template <int G, int P, int T0>
 __global__ void __launch_bounds__(256, 2)
-align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
+align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
 {
+    if (*La->choice != kid) return;                // another candidate takes the plain pairs of this batch (record_kernel)
     static_assert(T0 <= 0 && T0 >= -7, "T0 = w - 8 * ceil(w / 8)");
     constexpr bool CORNER_BLOCKS = (T0 + 8 < 7);   // blocks (0, W-1) and (pql-1, pql-W) are cut as well
     constexpr int S = 2 * P, GS = G * S;
@@ -727,7 +728,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm)
 // host side
 // ---------------------------------------------------------------------------------------------------
 template <int G, int P, int T0>
-static hipError_t launch_align16_t(const AlignLaunch& L, hipStream_t st)
+static hipError_t launch_align16_t(const AlignLaunch& L, int kid, hipStream_t st)
 {
     const int groups_per_block = (256 / 64) * (64 / G);
     int blocks = (L.n + groups_per_block - 1) / groups_per_block;
@@ -735,11 +736,11 @@ static hipError_t launch_align16_t(const AlignLaunch& L, hipStream_t st)
     if (L.max_blocks_override > 0) max_blocks = L.max_blocks_override;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((align16_kernel<G, P, T0>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
+    hipLaunchKernelGGL((align16_kernel<G, P, T0>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p, kid);
     return hipGetLastError();
 }
 
-typedef hipError_t (*launch16_fn)(const AlignLaunch&, hipStream_t);
+typedef hipError_t (*launch16_fn)(const AlignLaunch&, int, hipStream_t);
 struct Cfg16 { int G, P; launch16_fn fn[8]; };        // fn[-T0]
 #define AGATHA16_CFG(G, P) {G, P, {launch_align16_t<G, P, 0>, launch_align16_t<G, P, -1>, launch_align16_t<G, P, -2>, launch_align16_t<G, P, -3>, \
                                    launch_align16_t<G, P, -4>, launch_align16_t<G, P, -5>, launch_align16_t<G, P, -6>, launch_align16_t<G, P, -7>}}
@@ -766,27 +767,20 @@ static const Cfg16* pick16(const AlignParams& p, int window_blocks)
     return nullptr;
 }
 
-bool align16_available(const AlignParams& p, int window_blocks) { return pick16(p, window_blocks) != nullptr; }
-
-// lane groups of the kernel's persistent grid (2 workgroups of 4 waves per CU): with fewer pairs than that the batch is
-// latency-bound and the int32 kernel's shorter steps win
-int align16_group_capacity(const AlignParams& p, int window_blocks, int num_cus)
+bool align16_config(const AlignParams& p, int window_blocks, int* G, int* P)
 {
     const Cfg16* c = pick16(p, window_blocks);
-    return c ? num_cus * 8 * (64 / c->G) : 0;
+    if (!c) return false;
+    *G = c->G; *P = c->P;
+    return true;
 }
 
-// launches the packed-int16 kernel (kind-0 pairs only) if a configuration exists for this window
-bool launch_align16(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st, hipError_t* err)
+hipError_t launch_align16(const AlignLaunch& L, int G, int P, int kid, hipStream_t st)
 {
-    *err = hipSuccess;
-    const Cfg16* c = pick16(L.p, window_blocks);
-    if (!c) return false;
     const int W = (L.p.band_width + 7) / 8, t0 = L.p.band_width - 8 * W;
-    if (G_out) *G_out = c->G;
-    if (S_out) *S_out = 2 * c->P;
-    *err = c->fn[-t0](L, st);
-    return true;
+    for (const Cfg16& c : kCfgs16)
+        if (c.G == G && c.P == P) return c.fn[-t0](L, kid, st);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace agatha

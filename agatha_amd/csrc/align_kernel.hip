@@ -164,8 +164,11 @@ __device__ __forceinline__ void build_profile(uint2* __restrict__ prof, uint32_t
 
 template <int G, int S, bool CMP>
 __global__ void __launch_bounds__(256, (S <= 3 ? 2 : 1))
-align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
+align_kernel(const AlignLaunch* __restrict__ La, AlignParams P, int kid, int takes2)
 {
+    // kid: index of this kernel among the candidates for the plain (kind-0) pairs, chosen on the device (record_kernel);
+    // takes2: this launch also takes the pairs the int16 kernel handed over / could not take (kind 2)
+    if (!CMP && !takes2 && *La->choice != kid) return;
     // Batch pointers are read from the launch record only where a pair starts or ends: keeping a dozen 64-bit
     // pointers live through the DP loop would push the band masks (30 SGPRs) into spills.
     constexpr int GS = G * S;
@@ -220,7 +223,7 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
         const bool need = !alive && !exhausted;
         if (__builtin_expect(__any(need), 0)) {
             int idx = 0;
-            if (need && k == 0) idx = (int)atomicAdd(La->queue + (CMP ? 2 : 1), 1u);
+            if (need && k == 0) idx = (int)atomicAdd(La->queue + (CMP ? 2 : takes2 ? 1 : 3), 1u);      // one queue head per launch
             idx = lane_read(idx, gbase);
             if (need) {
                 if (idx >= La->n) exhausted = true;
@@ -228,10 +231,10 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P)
                     pair = (int)La->order[idx];
                     // two launches share the work: this instantiation only takes the pairs of its kind (the profile
                     // kernel skips pairs with letters outside ACGTN, the compare kernel takes exactly those)
-                    // pair kinds: 0 = plain letters, 1 = letters outside ACGTN (compare kernel), 2 = handed over by the
-                    // packed-int16 kernel.  The int16 kernel (when launched, use16) takes kind 0.
+                    // pair kinds: 0 = plain letters (the chosen candidate kernel), 1 = letters outside ACGTN (compare
+                    // kernel), 2 = handed over by / withheld from the packed-int16 kernel (int32 profile kernel)
                     const int kind = La->exotic[pair];
-                    const bool mine = CMP ? (La->force_cmp || kind == 1) : (kind == 2 || (kind == 0 && !La->use16));
+                    const bool mine = CMP ? (La->force_cmp || kind == 1) : ((takes2 && kind == 2) || (kind == 0 && *La->choice == kid));
                     if (mine) {
                     Q = (int)La->qlens[pair]; R = (int)La->tlens[pair];
                     pq = (gptr_t)(La->packed_q + (La->qoffs[pair] >> 3));
@@ -458,18 +461,31 @@ __global__ void sort_hist_kernel(const uint32_t* __restrict__ qlens, const uint3
 }
 
 // one workgroup: exclusive scan of the histogram from the LONGEST bucket down
-__global__ void sort_scan_kernel(uint32_t* __restrict__ hist, uint32_t nbuckets)
+__global__ void sort_scan_kernel(uint32_t* __restrict__ hist, uint32_t nbuckets, float* __restrict__ totals)
 {
     __shared__ uint32_t part[256];
+    __shared__ float fsum[256], fmax[256];
     const uint32_t per = (nbuckets + 255) / 256;
     const uint32_t t = threadIdx.x;
     uint32_t sum = 0;
+    float steps_sum = 0.f, steps_max = 0.f;          // what the kernel choice needs: total and longest step count
     for (uint32_t j = 0; j < per; j++) {
         const uint32_t b = t * per + j;
-        if (b < nbuckets) sum += hist[nbuckets - 1 - b];
+        if (b < nbuckets) {
+            const uint32_t bucket = nbuckets - 1 - b, c = hist[bucket];
+            sum += c;
+            const float st = 4.f * (float)bucket + 2.f;   // sort_key: bucket = steps >> 2
+            steps_sum += (float)c * st;
+            if (c) steps_max = fmaxf(steps_max, st);
+        }
     }
-    part[t] = sum;
+    part[t] = sum; fsum[t] = steps_sum; fmax[t] = steps_max;
     __syncthreads();
+    if (t == 0) {
+        float a = 0.f, m = 0.f;
+        for (int j = 0; j < 256; j++) { a += fsum[j]; m = fmaxf(m, fmax[j]); }
+        totals[0] = a; totals[1] = m;
+    }
     if (t == 0) { uint32_t acc = 0; for (int j = 0; j < 256; j++) { const uint32_t v = part[j]; part[j] = acc; acc += v; } }
     __syncthreads();
     uint32_t acc = part[t];
@@ -630,8 +646,9 @@ hipError_t launch_seq_ops(const uint8_t* unpacked, uint32_t* packed, const uint3
 // ---------------------------------------------------------------------------------------------------
 // host-side launchers (called from capi.cpp through kernels.h)
 // ---------------------------------------------------------------------------------------------------
+// which: 0 = profile kernel for candidate `kid`, 1 = profile kernel that also takes kind 2, 2 = compare kernel
 template <int G, int S>
-static hipError_t launch_align_t(const AlignLaunch& L, hipStream_t st)
+static hipError_t launch_align_t(const AlignLaunch& L, int which, int kid, hipStream_t st)
 {
     // enough groups for every pair, capped by what the chip can keep resident (2 waves/SIMD = 8 waves/CU)
     const int groups_per_block = (256 / 64) * (64 / G);
@@ -640,14 +657,12 @@ static hipError_t launch_align_t(const AlignLaunch& L, hipStream_t st)
     if (L.max_blocks_override > 0) max_blocks = L.max_blocks_override;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    // profile kernel for the plain pairs, compare kernel for the (usually zero) pairs with other letters: the second
-    // launch only walks the queue when there is nothing for it
-    if (!L.force_cmp) hipLaunchKernelGGL((align_kernel<G, S, false>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
-    hipLaunchKernelGGL((align_kernel<G, S, true>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p);
+    if (which == 2) hipLaunchKernelGGL((align_kernel<G, S, true>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p, -1, 0);
+    else hipLaunchKernelGGL((align_kernel<G, S, false>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p, kid, which);
     return hipGetLastError();
 }
 
-struct Cfg { int G, S; hipError_t (*fn)(const AlignLaunch&, hipStream_t); };
+struct Cfg { int G, S; hipError_t (*fn)(const AlignLaunch&, int, int, hipStream_t); };
 static const Cfg kCfgs[] = {       // ascending G*S
     {16, 1, launch_align_t<16, 1>}, {16, 2, launch_align_t<16, 2>}, {16, 3, launch_align_t<16, 3>},
     {32, 2, launch_align_t<32, 2>}, {64, 1, launch_align_t<64, 1>}, {32, 3, launch_align_t<32, 3>},
@@ -665,7 +680,20 @@ int key_bits_for_window(int window_blocks)
     return -1;
 }
 
-__global__ void record_kernel(AlignLaunch L, AlignLaunch* rec) { *rec = L; L.queue[0] = 0u; L.queue[1] = 0u; L.queue[2] = 0u; }
+// Writes the launch record, resets the queue heads and picks the kernel for the plain pairs: the candidate with the
+// smallest max(longest pair alone, whole batch spread over the candidate's lane groups).  A batch with a few very
+// long pairs is bound by their latency (fewer blocks per lane and step win), a uniform one by throughput.
+__global__ void record_kernel(AlignLaunch L, AlignLaunch* rec)
+{
+    *rec = L; L.queue[0] = 0u; L.queue[1] = 0u; L.queue[2] = 0u; L.queue[3] = 0u;
+    const float total = L.totals[0], longest = L.totals[1];
+    int best = 0; float bestc = 3.4e38f;
+    for (int c = 0; c < L.ncand; c++) {
+        const float cost = fmaxf(longest * L.cand[c].t_lat, total * L.cand[c].t_load / (float)L.cand[c].capacity);
+        if (cost < bestc) { bestc = cost; best = c; }
+    }
+    *L.choice = best;
+}
 
 hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st)
 {
@@ -674,33 +702,84 @@ hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st)
 }
 
 hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint32_t* hist, uint32_t nbuckets,
-                       uint32_t* order, hipStream_t st)
+                       uint32_t* order, float* totals, hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(hist, 0, sizeof(uint32_t) * nbuckets, st);
     if (e != hipSuccess) return e;
     const int blocks = (n + 255) / 256;
     hipLaunchKernelGGL(sort_hist_kernel, dim3(blocks), dim3(256), 0, st, qlens, tlens, n, hist, nbuckets);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(256), 0, st, hist, nbuckets);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(256), 0, st, hist, nbuckets, totals);
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks), dim3(256), 0, st, qlens, tlens, n, hist, nbuckets, order);
     return hipGetLastError();
 }
 
+// Throughput shape: the smallest G*S that holds the window (most pairs per wave, fullest lanes).  Latency shape: 64 lanes
+// per pair with fewer slots, so that a lane sweeps fewer blocks per step (results do not depend on the shape).
+static void pick_shapes(int window_blocks, const Cfg** thr, const Cfg** lat)
+{
+    *thr = nullptr; *lat = nullptr;
+    for (const Cfg& c : kCfgs)
+        if (c.G * c.S >= window_blocks) { *thr = &c; break; }
+    if (!*thr) return;
+    for (const Cfg& c : kCfgs)
+        if (c.G == 64 && c.G * c.S >= window_blocks && c.S < (*thr)->S) { *lat = &c; break; }
+}
+
+// Step-time model of the candidates (microseconds per step of one pair, measured on MI355X: profiles/r01_v4): a lane
+// sweeps S blocks per step; two waves share a SIMD when the chip is full (S <= 3: 2 waves/SIMD resident).
+static KernelChoice int32_choice(const Cfg& c, int num_cus)
+{
+    KernelChoice k;
+    k.kind = 0; k.G = c.G; k.S = c.S;
+    k.t_lat = 2.3f * c.S; k.t_load = (c.S <= 3 ? 3.3f : 2.3f) * c.S;
+    k.capacity = num_cus * (c.S <= 3 ? 8 : 4) * (64 / c.G);
+    return k;
+}
+
+hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool force16)
+{
+    const Cfg *thr, *lat;
+    pick_shapes(window_blocks, &thr, &lat);
+    if (!thr) return hipErrorInvalidValue;
+    L.ncand = 0;
+    int G16 = 0, P16 = 0;
+    const bool have16 = !disable16 && !L.force_cmp && align16_config(L.p, window_blocks, &G16, &P16);
+    if (have16) {
+        KernelChoice k;
+        k.kind = 1; k.G = G16; k.S = 2 * P16;
+        k.t_lat = 3.5f * P16; k.t_load = 5.0f * P16;
+        k.capacity = L.num_cus * 8 * (64 / G16);
+        L.cand[L.ncand++] = k;
+    }
+    if (!(have16 && force16)) {
+        L.cand[L.ncand++] = int32_choice(*thr, L.num_cus);
+        if (lat) L.cand[L.ncand++] = int32_choice(*lat, L.num_cus);
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st)
 {
-    // Throughput choice: the smallest G*S that holds the window (most pairs per wave, fullest lanes).
-    const Cfg* pick = nullptr;
-    for (const Cfg& c : kCfgs)
-        if (c.G * c.S >= window_blocks) { pick = &c; break; }
-    if (!pick) return hipErrorInvalidValue;
-    // Latency choice for small batches: when even 64 lanes per pair leave SIMDs idle, spread each pair over a whole
-    // wave so that a lane sweeps fewer blocks per step (results do not depend on the shape).
-    if (L.n <= L.num_cus * 4) {
-        for (const Cfg& c : kCfgs)
-            if (c.G == 64 && c.G * c.S >= window_blocks && c.S < pick->S) { pick = &c; break; }
+    const Cfg *thr, *lat;
+    pick_shapes(window_blocks, &thr, &lat);
+    if (!thr) return hipErrorInvalidValue;
+    if (G_out) *G_out = thr->G;
+    if (S_out) *S_out = thr->S;
+    if (L.force_cmp) return thr->fn(L, 2, -1, st);
+    // candidates for the plain pairs in record order; the throughput shape also takes the kind-2 pairs, so it always runs
+    // (after the int16 kernel, which produces them) even when it is not a candidate
+    int kid_thr = -2;
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < L.ncand && e == hipSuccess; c++) {
+        const KernelChoice& k = L.cand[c];
+        if (k.kind == 1) e = launch_align16(L, k.G, k.S / 2, c, st);
+        else if (k.G == thr->G && k.S == thr->S) kid_thr = c;
+        else if (lat) e = lat->fn(L, 0, c, st);
     }
-    if (G_out) *G_out = pick->G;
-    if (S_out) *S_out = pick->S;
-    return pick->fn(L, st);
+    if (e != hipSuccess) return e;
+    e = thr->fn(L, 1, kid_thr, st);
+    if (e != hipSuccess) return e;
+    return thr->fn(L, 2, -1, st);          // compare kernel: walks the queue only if pairs with other letters exist
 }
 
 hipError_t launch_pack(const uint8_t* unpacked, uint32_t nbytes, uint32_t* packed, hipStream_t st)

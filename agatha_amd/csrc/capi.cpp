@@ -125,7 +125,9 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     agatha::AlignLaunch* rec = (agatha::AlignLaunch*)ws;   ws += round_up(sizeof(agatha::AlignLaunch));
     uint8_t* exotic = (uint8_t*)ws;
 
-    HIPCHK(agatha::launch_sort(d_query_lens, d_target_lens, (int)n_alns, hist, kBuckets, order, st));
+    float* totals = (float*)(queue + 8);         // inside the 256-byte queue block: [8] step totals, [10] kernel choice
+    int* choice = (int*)(queue + 10);
+    HIPCHK(agatha::launch_sort(d_query_lens, d_target_lens, (int)n_alns, hist, kBuckets, order, totals, st));
 
     agatha::AlignLaunch L;
     L.packed_q = d_packed_query; L.packed_t = d_packed_target;
@@ -138,23 +140,18 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.force_cmp = (sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     HIPCHK(agatha::launch_exotic(L, st));
     { const char* e = getenv("AGATHA_AMD_MAX_BLOCKS"); L.max_blocks_override = e ? atoi(e) : 0; }
-    // the packed-int16 kernel takes the plain pairs first when the scores and the band allow it
-    // and the batch has enough pairs to fill its lane groups (AGATHA_AMD_NO_INT16=1 keeps everything on the int32
-    // kernels, AGATHA_AMD_FORCE_INT16=1 uses the int16 kernel for small batches too: A/B runs, tests)
+    // Candidates for the plain pairs: the packed-int16 kernel when the scores and the band allow it, the int32 kernel
+    // in its throughput shape and in its latency shape; which one runs is decided on the device from the batch's length
+    // histogram (record_kernel).  AGATHA_AMD_NO_INT16=1 removes the int16 kernel, AGATHA_AMD_FORCE_INT16=1 makes it the
+    // only candidate (A/B runs, tests).
     { const char* e = getenv("AGATHA_AMD_NO_INT16");
       const char* f = getenv("AGATHA_AMD_FORCE_INT16");
-      const int cap = agatha::align16_group_capacity(L.p, (int)window, L.num_cus);
-      L.use16 = (!L.force_cmp && !(e && atoi(e)) && cap > 0 && ((f && atoi(f)) || (long)n_alns >= (long)cap)) ? 1 : 0; }
+      L.choice = choice; L.totals = totals;
+      HIPCHK(agatha::plan_align(L, (int)window, e && atoi(e), f && atoi(f))); }
+    g_last16 = (L.ncand > 0 && L.cand[0].kind == 1) ? ((L.cand[0].G << 8) | L.cand[0].S) : 0;
     L.self_dev = rec;
-    HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record + queue head reset, stream-ordered
+    HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record, queue head reset, kernel choice; stream-ordered
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));
-    g_last16 = 0;
-    if (L.use16) {
-        hipError_t e16 = hipSuccess;
-        int G16 = 0, S16 = 0;
-        if (agatha::launch_align16(L, (int)window, &G16, &S16, st, &e16)) g_last16 = (G16 << 8) | S16;
-        HIPCHK(e16);
-    }
     HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st));
     if (g_ev1) HIPCHK(hipEventRecord(g_ev1, st));
     return 0;
@@ -165,6 +162,22 @@ void agatha_amd_set_kernel_events(void* ev_begin, void* ev_end) { g_ev0 = (hipEv
 void agatha_amd_last_config(int* G, int* S) { if (G) *G = g_lastG; if (S) *S = g_lastS; }
 
 int agatha_amd_last_int16_config(void) { return g_last16; }
+
+int agatha_amd_kernel_choice(void* stream, const void* d_workspace, uint32_t n_alns, int out[3])
+{
+    if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
+    const char* ws = (const char*)d_workspace;
+    ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets);
+    int choice = 0;
+    agatha::AlignLaunch rec;
+    hipError_t e = hipMemcpyAsync(&choice, ws + 10 * sizeof(unsigned int), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&rec, ws + kAlign, sizeof(rec), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "agatha_amd_kernel_choice");
+    if (choice < 0 || choice >= rec.ncand) return AGATHA_AMD_EINVAL;
+    out[0] = rec.cand[choice].kind; out[1] = rec.cand[choice].G; out[2] = rec.cand[choice].S;
+    return 0;
+}
 
 int agatha_amd_pair_kinds(void* stream, const void* d_workspace, uint32_t n_alns, uint32_t counts[3])
 {

@@ -76,6 +76,7 @@ def load_library():
     lib.agatha_amd_last_config.restype = None
     lib.agatha_amd_last_int16_config.restype = C.c_int
     lib.agatha_amd_pair_kinds.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.agatha_amd_kernel_choice.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.agatha_amd_free.argtypes = [vp]
     lib.agatha_amd_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -97,7 +98,7 @@ def load_library():
 EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack",
-    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -197,6 +198,14 @@ class DeviceBatch:
                                        self.d_res[0].ptr, self.d_res[1].ptr, self.d_res[2].ptr,
                                        self.d_ws.ptr, self.ws_bytes))
 
+    def kernel_choice(self, stream=None):
+        """("int32" | "int16", lanes per pair, slots per lane) of the kernel the device chose for the plain pairs."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        c = (C.c_int * 3)()
+        _chk(lib, lib.agatha_amd_kernel_choice(st, self.d_ws.ptr, self.n, c))
+        return ("int16" if c[0] else "int32", int(c[1]), int(c[2]))
+
     def pair_kinds(self, stream=None):
         """(plain, other letters, taken over by the int32 profile kernel) pair counts of the last align()."""
         lib = self.eng.lib
@@ -252,7 +261,8 @@ class Engine:
         return g.value, s.value
 
     def last_int16_config(self):
-        """(lanes per pair, slots per lane) of the packed-int16 kernel if the last align launched it, else None."""
+        """(lanes per pair, slots per lane) of the packed-int16 kernel if it was a candidate in the last align, else
+        None; DeviceBatch.kernel_choice() tells which candidate the device picked."""
         v = int(self.lib.agatha_amd_last_int16_config())
         return (v >> 8, v & 255) if v else None
 

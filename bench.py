@@ -194,10 +194,8 @@ def main():
     kms = [eng.elapsed_ms(e0, e1) for e0, e1 in kev] if a.steps else [float("nan")]
     kernel_ms = float(np.mean(kms))
     G, S = eng.last_config()
-    cfg16 = eng.last_int16_config()         # the packed-int16 kernel takes the plain pairs when scores / band allow it
-    kind = "int16" if cfg16 else "int32"
-    kname = f"agatha::align16_kernel<{cfg16[0]},{cfg16[1] // 2}>" if cfg16 else f"agatha::align_kernel<{G},{S},false>"
-    Gd, Sd = cfg16 if cfg16 else (G, S)
+    kind, Gd, Sd = b.kernel_choice(stream)  # which candidate kernel the device picked for the plain pairs
+    kname = f"agatha::align16_kernel<{Gd},{Sd // 2}>" if kind == "int16" else f"agatha::align_kernel<{Gd},{Sd},false>"
 
     if rank == 0:
         ms_per_step = elapsed / max(a.steps, 1) * 1e3

@@ -94,12 +94,19 @@ void agatha_amd_set_kernel_events(void* ev_begin, void* ev_end);
 /* lane-group shape the last agatha_amd_align() of this thread used (diagnostics for bench.py / DESIGN.md) */
 void agatha_amd_last_config(int* lanes_per_pair, int* slots_per_lane);
 
-/* (lanes_per_pair << 8) | slots_per_lane of the packed-int16 kernel if the last agatha_amd_align() of this thread
- * launched it (plain-letter pairs run there first; pairs it hands back and pairs with other letters run on the int32
- * kernels), 0 if it did not: scores or band outside its domain, or fewer pairs than its persistent grid has lane groups
- * (a latency-bound batch runs faster on the int32 kernel).  Environment: AGATHA_AMD_NO_INT16=1 keeps every pair on the
- * int32 kernels, AGATHA_AMD_FORCE_INT16=1 uses the int16 kernel for small batches as well. */
+/* (lanes_per_pair << 8) | slots_per_lane of the packed-int16 kernel if it was a CANDIDATE in the last
+ * agatha_amd_align() of this thread (scores and band inside its domain), 0 if not.  Whether it ran is the device's
+ * choice (agatha_amd_kernel_choice).  Environment: AGATHA_AMD_NO_INT16=1 removes it from the candidates,
+ * AGATHA_AMD_FORCE_INT16=1 makes it the only one. */
 int agatha_amd_last_int16_config(void);
+
+/* Diagnostics: which candidate kernel the device chose for the plain pairs of the last agatha_amd_align() on this
+ * workspace: out[0] = 0 int32 profile kernel / 1 packed-int16 kernel, out[1] = lanes per pair, out[2] = slots per lane.
+ * (Candidates: the int16 kernel if scores and band allow it, the int32 kernel with the smallest lane group that holds the
+ * band, and the int32 kernel with 64 lanes per pair; the device picks the one with the smallest estimated time from
+ * the batch's length histogram -- latency of the longest pair against throughput over the whole batch.)  Synchronises
+ * the stream. */
+int agatha_amd_kernel_choice(void* stream, const void* d_workspace, uint32_t n_alns, int out[3]);
 
 /* Diagnostics: how the last agatha_amd_align() on this workspace routed its n_alns pairs.  counts[0] = plain pairs
  * (aligned by the packed-int16 kernel when it ran, else by the int32 profile kernel), counts[1] = pairs with letters

@@ -23,15 +23,22 @@ def eng():
     del os.environ["AGATHA_AMD_FORCE_INT16"]
 
 
-def test_small_batches_stay_on_the_int32_kernel(eng):
+def test_device_side_kernel_choice(eng):
+    """Without the override the device picks the kernel from the length histogram: a small batch is latency-bound (int32
+    kernel, 64 lanes per pair), a large uniform one throughput-bound (int16 kernel)."""
     import agatha_amd
-    qs, ts = WL.cfg_c1(n=64, seed=3)
-    qb, qo, ql = WL.make_batch(qs)
-    tb, to, tl = WL.make_batch(ts)
     del os.environ["AGATHA_AMD_FORCE_INT16"]
     try:
-        eng.align_host_batch(qb, tb, qo, to, ql, tl, agatha_amd.Scores.make(**BASE))
-        assert eng.last_int16_config() is None
+        for n, expect in ((64, ("int32", 64, 2)), (9000, ("int16", 16, 6))):
+            qs, ts = WL.make_pairs(3, n, lambda r: int(r.integers(900, 1100)), 0.03, 0.03, 0.04)
+            qb, qo, ql = WL.make_batch(qs)
+            tb, to, tl = WL.make_batch(ts)
+            b = eng.batch(qb, tb, qo, to, ql, tl)
+            try:
+                b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**BASE), use_len_hint=False)
+                assert b.kernel_choice() == expect
+            finally:
+                b.free()
     finally:
         os.environ["AGATHA_AMD_FORCE_INT16"] = "1"
 

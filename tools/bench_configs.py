@@ -41,7 +41,7 @@ for name, gen, p in cfgs:
     b.download(); eng.synchronize()
     best = min(ms)
     out[name] = dict(pairs=len(ql), nominal_cells=cells, ms=best, gcups_nominal=cells / best / 1e6,
-                     pairs_per_s=len(ql) / best * 1e3, cfg=eng.last_config(), int16_cfg=eng.last_int16_config(),
+                     pairs_per_s=len(ql) / best * 1e3, cfg=eng.last_config(), choice=b.kernel_choice(),
                      kinds=b.pair_kinds(), gen_s=round(time.time() - t0, 1))
     print(name, out[name], flush=True)
     b.free()
