@@ -744,8 +744,9 @@ typedef hipError_t (*launch16_fn)(const AlignLaunch&, int, hipStream_t);
 struct Cfg16 { int G, P; launch16_fn fn[8]; };        // fn[-T0]
 #define AGATHA16_CFG(G, P) {G, P, {launch_align16_t<G, P, 0>, launch_align16_t<G, P, -1>, launch_align16_t<G, P, -2>, launch_align16_t<G, P, -3>, \
                                    launch_align16_t<G, P, -4>, launch_align16_t<G, P, -5>, launch_align16_t<G, P, -6>, launch_align16_t<G, P, -7>}}
-static const Cfg16 kCfgs16[] = {       // ascending G * 2P: windows of 32, 64, 96, 128, 192 blocks
+static const Cfg16 kCfgs16[] = {       // ascending G * 2P: windows of 32, 64, 96, 128, 192 blocks; then the latency shapes
     AGATHA16_CFG(16, 1), AGATHA16_CFG(16, 2), AGATHA16_CFG(16, 3), AGATHA16_CFG(32, 2), AGATHA16_CFG(32, 3),
+    AGATHA16_CFG(64, 1), AGATHA16_CFG(64, 2),
 };
 
 bool agatha16_scores_ok(const AlignParams& p)
@@ -763,15 +764,18 @@ static const Cfg16* pick16(const AlignParams& p, int window_blocks)
 {
     if (!agatha16_scores_ok(p)) return nullptr;
     for (const Cfg16& c : kCfgs16)
-        if (c.G * 2 * c.P >= window_blocks) return (c.G * 2 * c.P <= 2 * window_blocks + 32) ? &c : nullptr;
+        if (c.G < 64 && c.G * 2 * c.P >= window_blocks) return (c.G * 2 * c.P <= 2 * window_blocks + 32) ? &c : nullptr;
     return nullptr;
 }
 
-bool align16_config(const AlignParams& p, int window_blocks, int* G, int* P)
+bool align16_config(const AlignParams& p, int window_blocks, int* G, int* P, int* GL, int* PL)
 {
     const Cfg16* c = pick16(p, window_blocks);
     if (!c) return false;
     *G = c->G; *P = c->P;
+    *GL = 0; *PL = 0;
+    for (const Cfg16& l : kCfgs16)            // latency shape: 64 lanes per pair, fewer register pairs per lane
+        if (l.G == 64 && l.G * 2 * l.P >= window_blocks && l.P < c->P) { *GL = l.G; *PL = l.P; break; }
     return true;
 }
 

@@ -742,14 +742,20 @@ hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool fo
     pick_shapes(window_blocks, &thr, &lat);
     if (!thr) return hipErrorInvalidValue;
     L.ncand = 0;
-    int G16 = 0, P16 = 0;
-    const bool have16 = !disable16 && !L.force_cmp && align16_config(L.p, window_blocks, &G16, &P16);
+    int G16 = 0, P16 = 0, GL16 = 0, PL16 = 0;
+    const bool have16 = !disable16 && !L.force_cmp && align16_config(L.p, window_blocks, &G16, &P16, &GL16, &PL16);
     if (have16) {
         KernelChoice k;
         k.kind = 1; k.G = G16; k.S = 2 * P16;
         k.t_lat = 3.5f * P16; k.t_load = 5.0f * P16;
         k.capacity = L.num_cus * 8 * (64 / G16);
         L.cand[L.ncand++] = k;
+        if (GL16 && !force16) {
+            k.G = GL16; k.S = 2 * PL16;
+            k.t_lat = 3.5f * PL16; k.t_load = 5.0f * PL16;
+            k.capacity = L.num_cus * 8 * (64 / GL16);
+            L.cand[L.ncand++] = k;
+        }
     }
     if (!(have16 && force16)) {
         L.cand[L.ncand++] = int32_choice(*thr, L.num_cus);

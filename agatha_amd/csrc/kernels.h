@@ -24,7 +24,7 @@ struct AlignLaunch {
     uint8_t* exotic;               // per pair kind: 0 = plain, 1 = holds letters outside ACGTN (compare kernel),
                                    // 2 = abandoned by the packed-int16 kernel (int32 profile kernel takes it)
     int ncand;                     // candidates for the kind-0 pairs, in launch order
-    KernelChoice cand[3];
+    KernelChoice cand[4];
     int* choice;                   // device: index of the candidate that takes the kind-0 pairs
     float* totals;                 // device: [0] sum of steps over the batch, [1] steps of the longest pair (sort_scan_kernel)
     int force_cmp;                 // 1 = scores do not fit the byte profile: compare path for every pair
@@ -41,8 +41,9 @@ struct AlignLaunch {
 hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool force16);
 hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st);
 int max_window_blocks();
-// packed-int16 kernel (align16_kernel.hip): the (G, P) it would use for this window, and its launcher
-bool align16_config(const AlignParams& p, int window_blocks, int* G, int* P);
+// packed-int16 kernel (align16_kernel.hip): the (G, P) of its throughput shape for this window and, if there is one with
+// fewer blocks per lane, of its latency shape (64 lanes per pair; *GL = 0 if none); and its launcher
+bool align16_config(const AlignParams& p, int window_blocks, int* G, int* P, int* GL, int* PL);
 hipError_t launch_align16(const AlignLaunch& L, int G, int P, int kid, hipStream_t st);
 int key_bits_for_window(int window_blocks);
 // writes L into *rec on the device (by-value kernel argument: no host-memory lifetime to care about) and zeroes *L.queue

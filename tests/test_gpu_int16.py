@@ -24,12 +24,12 @@ def eng():
 
 
 def test_device_side_kernel_choice(eng):
-    """Without the override the device picks the kernel from the length histogram: a small batch is latency-bound (int32
-    kernel, 64 lanes per pair), a large uniform one throughput-bound (int16 kernel)."""
+    """Without the override the device picks the kernel from the length histogram: a small batch is latency-bound (64
+    lanes per pair, one register pair per lane), a large uniform one throughput-bound (16 lanes per pair, three)."""
     import agatha_amd
     del os.environ["AGATHA_AMD_FORCE_INT16"]
     try:
-        for n, expect in ((64, ("int32", 64, 2)), (9000, ("int16", 16, 6))):
+        for n, expect in ((64, ("int16", 64, 2)), (9000, ("int16", 16, 6))):
             qs, ts = WL.make_pairs(3, n, lambda r: int(r.integers(900, 1100)), 0.03, 0.03, 0.04)
             qb, qo, ql = WL.make_batch(qs)
             tb, to, tl = WL.make_batch(ts)
