@@ -77,3 +77,19 @@ def test_cli_argument_contract(tmp_path):
     # multi-letter option packs are refused
     r = subprocess.run([MANUAL, "-sp", "1", str(tmp_path / "a"), str(tmp_path / "b")], capture_output=True, text=True)
     assert r.returncode == 1 and "Wrong argument" in r.stderr
+
+
+def test_avg_time_contract(tmp_path):
+    """Post-processing of the driver script (reference misc/avg_time.py:14-44): sum of the raw log / iterations, merged
+    into the JSON; "NaN" for a missing or empty raw file."""
+    import json
+    from agatha_amd import avg_time
+    raw = tmp_path / "raw.log"
+    out = tmp_path / "time.json"
+    raw.write_text("1.5\n2.5\n4\n")
+    assert avg_time.main(["AGAThA", "test", str(raw), str(out), "2"]) == 0
+    assert json.loads(out.read_text()) == {"AGAThA": {"test": 4.0}}
+    (tmp_path / "empty.log").write_text("")
+    avg_time.main(["AGAThA", "empty", str(tmp_path / "empty.log"), str(out), "3"])
+    avg_time.main(["other", "gone", str(tmp_path / "missing.log"), str(out), "3"])
+    assert json.loads(out.read_text()) == {"AGAThA": {"test": 4.0, "empty": "NaN"}, "other": {"gone": "NaN"}}
