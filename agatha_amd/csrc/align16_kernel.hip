@@ -547,30 +547,23 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                 // same constants (its new column is always beyond the first band width)
                 const uint32_t RSm = ~ACTm & ~lt_mask(ce2, q2, F15);
                 const uint32_t INm = RSm | ADm;
-                if (__any(INm != 0u)) {
-                    if (__builtin_expect(__any(RSm != 0u && (ra <= W || rb <= W)), 0)) {
-                        uint32_t ha[8], fa[8], ca, hb[8], fb[8], cbv;
-                        int ral = ra, rbl = rb;
-                        asm volatile("" : "+v"(ral), "+v"(rbl));
-                        init_half(ral, R, w, W, gapoe, ge, base, ha, fa, ca);
-                        init_half(rbl, R, w, W, gapoe, ge, base, hb, fb, cbv);
+                // constants first (no branch: some lane of the wave needs it on almost every step) ...
 #pragma unroll
-                        for (int m = 0; m < 8; m++) { H[p][m] = bfi(RSm, pk2(ha[m], hb[m]), H[p][m]); F[p][m] = bfi(RSm, pk2(fa[m], fb[m]), F[p][m]); }
-                        CORNER[p] = bfi(RSm, pk2(ca, cbv), CORNER[p]);
+                for (int m = 0; m < 8; m++) {
+                    H[p][m] = bfi(INm, m < 7 ? HINIT : H7INIT, H[p][m]);
+                    F[p][m] = bfi(INm, m == 0 ? F0INIT : FINIT, F[p][m]);
+                }
+                CORNER[p] = bfi(INm, CINIT, CORNER[p]);
+                // ... then the real boundary values of the first band width of columns (only while a pair starts)
+                if (__builtin_expect(__any(RSm != 0u && (ra <= W || rb <= W)), 0)) {
+                    uint32_t ha[8], fa[8], ca, hb[8], fb[8], cbv;
+                    int ral = ra, rbl = rb;
+                    asm volatile("" : "+v"(ral), "+v"(rbl));
+                    init_half(ral, R, w, W, gapoe, ge, base, ha, fa, ca);
+                    init_half(rbl, R, w, W, gapoe, ge, base, hb, fb, cbv);
 #pragma unroll
-                        for (int m = 0; m < 8; m++) {
-                            H[p][m] = bfi(ADm, m < 7 ? HINIT : H7INIT, H[p][m]);
-                            F[p][m] = bfi(ADm, m == 0 ? F0INIT : FINIT, F[p][m]);
-                        }
-                        CORNER[p] = bfi(ADm, CINIT, CORNER[p]);
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < 8; m++) {
-                            H[p][m] = bfi(INm, m < 7 ? HINIT : H7INIT, H[p][m]);
-                            F[p][m] = bfi(INm, m == 0 ? F0INIT : FINIT, F[p][m]);
-                        }
-                        CORNER[p] = bfi(INm, CINIT, CORNER[p]);
-                    }
+                    for (int m = 0; m < 8; m++) { H[p][m] = bfi(RSm, pk2(ha[m], hb[m]), H[p][m]); F[p][m] = bfi(RSm, pk2(fa[m], fb[m]), F[p][m]); }
+                    CORNER[p] = bfi(RSm, pk2(ca, cbv), CORNER[p]);
                 }
                 if (__any(ADm != 0u)) {
                     if (ADm & 1u) build_profile5(prof0 + (2 * p) * (4 * 64), rwa, plut);

@@ -10,11 +10,16 @@ python3 - <<PY
 import json,csv,glob,collections
 b=json.load(open("gpurun_out/bench_$TAG.json")); print("GCUPS",round(b["value"],1),"kernel_ms",round(b["kernel_ms"],2),"kernel",b["config"]["kernel"])
 agg=collections.defaultdict(list)
+kn=b["config"]["kernel"].replace("agatha::","")           # e.g. align16_kernel<16,3>
+base,args=kn.split("<"); args=args.rstrip(">").split(",")
 for f in glob.glob("gpurun_out/pmc_$TAG/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if b["config"]["kernel"].split("::")[1].split("<")[0] + "<" in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        n=r["Kernel_Name"]
+        if base+"<"+", ".join(args)+"," in n.replace("true","1") or base+"<"+", ".join(args)+">" in n:
+            if ", true>" in n: continue
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m={k:sum(v)/len(v) for k,v in agg.items()}
-cells=1.367e11
+cells=1.4366e11
 print({k:"%.3e"%v for k,v in m.items()})
 if "SQ_INSTS_VALU" in m: print("VALU lane-ops/cell %.2f"%(m["SQ_INSTS_VALU"]*64/cells), "SALU/VALU %.2f"%(m["SQ_INSTS_SALU"]/m["SQ_INSTS_VALU"]))
 PY
