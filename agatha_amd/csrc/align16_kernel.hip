@@ -360,7 +360,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                             if (k == 0) { La->score[pair] = INT_MIN; La->qend[pair] = -1; La->tend[pair] = -1; }
                             alive = false;
                         } else if (pql + GS >= 32760 || prl + GS >= 32760) {      // indices are 16 bits wide here
-                            if (k == 0) La->exotic[pair] = 2;
+                            if (k == 0) { La->exotic[pair] = 2; atomicAdd(La->kind_counts + 1, 1u); }
                             alive = false;
                         }
                     }
@@ -707,7 +707,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
         }
         if (__builtin_expect(bail && alive, 0)) {
             // hand the pair to the int32 kernel (launched after this one on the same stream)
-            if (k == 0) La->exotic[pair] = 2;
+            if (k == 0) { La->exotic[pair] = 2; atomicAdd(La->kind_counts + 1, 1u); }
             alive = false;
         } else if (__builtin_expect(finished, 0)) {
             if (k == 0) { La->score[pair] = best; La->qend[pair] = best_q; La->tend[pair] = best_t; }   // :359-363

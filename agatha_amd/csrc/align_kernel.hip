@@ -169,6 +169,8 @@ align_kernel(const AlignLaunch* __restrict__ La, AlignParams P, int kid, int tak
     // kid: index of this kernel among the candidates for the plain (kind-0) pairs, chosen on the device (record_kernel);
     // takes2: this launch also takes the pairs the int16 kernel handed over / could not take (kind 2)
     if (!CMP && !takes2 && *La->choice != kid) return;
+    if (!CMP && takes2 && *La->choice != kid && La->kind_counts[1] == 0u) return;      // nothing was handed over
+    if (CMP && !La->force_cmp && La->kind_counts[0] == 0u) return;                      // no pair with other letters
     // Batch pointers are read from the launch record only where a pair starts or ends: keeping a dozen 64-bit
     // pointers live through the DP loop would push the band masks (30 SGPRs) into spills.
     constexpr int GS = G * S;
@@ -557,7 +559,8 @@ __device__ __forceinline__ bool word_has_n(uint32_t v, uint32_t nbases)
 __global__ void __launch_bounds__(256)
 exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__ packed_t,
               const uint32_t* __restrict__ qlens, const uint32_t* __restrict__ tlens,
-              const uint32_t* __restrict__ qoffs, const uint32_t* __restrict__ toffs, uint8_t* __restrict__ exotic, int n)
+              const uint32_t* __restrict__ qoffs, const uint32_t* __restrict__ toffs, uint8_t* __restrict__ exotic, int n,
+              unsigned int* __restrict__ kind_counts)
 {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -574,7 +577,11 @@ exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict_
         const uint32_t nb = (tlens[p] + 7u) >> 3;
         for (uint32_t i = lane; i < nb; i += 64u) plain = plain && word_is_plain(b[i]);
         const bool all_plain = __all(plain), any_qn = __any(qn);
-        if (lane == 0) exotic[p] = all_plain ? (any_qn ? 2 : 0) : 1;
+        if (lane == 0) {
+            const int kind = all_plain ? (any_qn ? 2 : 0) : 1;
+            exotic[p] = (uint8_t)kind;
+            if (kind) atomicAdd(kind_counts + (kind - 1), 1u);
+        }
     }
 }
 
@@ -584,7 +591,7 @@ hipError_t launch_exotic(const AlignLaunch& L, hipStream_t st)
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(exotic_kernel, dim3(blocks), dim3(256), 0, st, L.packed_q, L.packed_t, L.qlens, L.tlens, L.qoffs,
-                       L.toffs, L.exotic, L.n);
+                       L.toffs, L.exotic, L.n, L.kind_counts);
     return hipGetLastError();
 }
 

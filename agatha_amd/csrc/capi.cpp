@@ -125,8 +125,10 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     agatha::AlignLaunch* rec = (agatha::AlignLaunch*)ws;   ws += round_up(sizeof(agatha::AlignLaunch));
     uint8_t* exotic = (uint8_t*)ws;
 
-    float* totals = (float*)(queue + 8);         // inside the 256-byte queue block: [8] step totals, [10] kernel choice
+    // inside the 256-byte queue block: [0..3] queue heads, [8] step totals, [10] kernel choice, [12] pair-kind counters
+    float* totals = (float*)(queue + 8);
     int* choice = (int*)(queue + 10);
+    HIPCHK(hipMemsetAsync(queue, 0, kAlign, st));
     HIPCHK(agatha::launch_sort(d_query_lens, d_target_lens, (int)n_alns, hist, kBuckets, order, totals, st));
 
     agatha::AlignLaunch L;
@@ -137,6 +139,7 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.p = {sc->match, sc->mismatch, sc->gap_open, sc->gap_extend, sc->slice_width, sc->z_threshold, sc->band_width};
     L.num_cus = num_cus();
     L.exotic = exotic;
+    L.kind_counts = queue + 12;
     L.force_cmp = (sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     HIPCHK(agatha::launch_exotic(L, st));
     { const char* e = getenv("AGATHA_AMD_MAX_BLOCKS"); L.max_blocks_override = e ? atoi(e) : 0; }

@@ -149,7 +149,13 @@ class DeviceBatch:
         self.d_res = [_DevBuf(lib, 4 * self.n) for _ in range(3)]
         self.ws_bytes = lib.agatha_amd_workspace_bytes(self.n)
         self.d_ws = _DevBuf(lib, self.ws_bytes)
-        self.res_host = np.zeros((3, self.n), np.int32)
+        # results land in pinned host memory (as the reference's cudaHostAlloc'd host_res, ctors.cpp): the D2H copy is
+        # then really asynchronous and the host can enqueue the next batch while this one runs
+        hp = C.c_void_p()
+        _chk(lib, lib.agatha_amd_host_alloc(C.byref(hp), 12 * self.n))
+        self._res_pinned = hp.value
+        self.res_host = np.ctypeslib.as_array((C.c_int32 * (3 * self.n)).from_address(hp.value)).reshape(3, self.n)
+        self.res_host[:] = 0
 
     def use_result_pointers(self, ptrs):
         """Write results into caller-owned device arrays (e.g. torch tensors used for the RCCL gather)."""
@@ -232,6 +238,10 @@ class DeviceBatch:
         return out
 
     def free(self):
+        if getattr(self, "_res_pinned", None):
+            self.res_host = None
+            self.eng.lib.agatha_amd_host_free(self._res_pinned)
+            self._res_pinned = None
         for b in [self.d_unp_q, self.d_unp_t, self.d_pk_q, self.d_pk_t, self.d_ws] + self.d_meta + self.d_res:
             b.free()
         for b in getattr(self, "_tmp", []):
