@@ -188,3 +188,25 @@ def test_ragged_lengths_around_block_edges(eng):
     for p in (BASE, dict(BASE, w=760, s=2)):
         got, exp = _run(eng, qs, ts, p)
         assert _same(got, exp)
+
+
+def test_pairs_longer_than_the_16_bit_block_indices(eng):
+    """The int16 kernel keeps block indices in 16 bits (sequences up to 262 k bases); a longer pair is handed to the
+    int32 kernel when it is drawn from the queue."""
+    import agatha_amd
+    p = dict(m=1, x=4, q=6, r=2, s=3, z=400, w=751)
+    rng = np.random.default_rng(77)
+    big = WL.random_seq(rng, 270000)
+    qs = [big.tobytes()] + [WL.random_seq(rng, 3000).tobytes() for _ in range(6)]
+    ts = [WL.mutate(rng, big, 0.01, 0.01, 0.01).tobytes()] + [WL.mutate(rng, np.frombuffer(q, np.uint8), 0.03, 0.03, 0.04).tobytes() for q in qs[1:]]
+    got, exp = _run(eng, qs, ts, p)
+    assert _same(got, exp)
+    assert int(exp[0][0]) > 200000
+    qb, qo, ql = WL.make_batch(qs)
+    tb, to, tl = WL.make_batch(ts)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p))
+        assert b.kernel_choice()[0] == "int16" and b.pair_kinds() == (6, 0, 1)
+    finally:
+        b.free()
