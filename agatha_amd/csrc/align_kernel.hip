@@ -699,7 +699,7 @@ __global__ void record_kernel(AlignLaunch L, AlignLaunch* rec)
         const float cost = fmaxf(longest * L.cand[c].t_lat, total * L.cand[c].t_load / (float)L.cand[c].capacity);
         if (cost < bestc) { bestc = cost; best = c; }
     }
-    *L.choice = best;
+    *L.choice = (L.force_choice >= 0 && L.force_choice < L.ncand) ? L.force_choice : best;
 }
 
 hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st)
@@ -732,13 +732,14 @@ static void pick_shapes(int window_blocks, const Cfg** thr, const Cfg** lat)
         if (c.G == 64 && c.G * c.S >= window_blocks && c.S < (*thr)->S) { *lat = &c; break; }
 }
 
-// Step-time model of the candidates (microseconds per step of one pair, measured on MI355X: profiles/r01_v4): a lane
-// sweeps S blocks per step; two waves share a SIMD when the chip is full (S <= 3: 2 waves/SIMD resident).
+// Step-time model of the candidates (microseconds per step of one pair, measured on MI355X with
+// tools/bench_candidates.py: profiles/r01_v5/candidates.txt): a lane sweeps S blocks (P register pairs) per step; two
+// waves share a SIMD when the chip is full (S <= 3: 2 waves/SIMD resident).
 static KernelChoice int32_choice(const Cfg& c, int num_cus)
 {
     KernelChoice k;
     k.kind = 0; k.G = c.G; k.S = c.S;
-    k.t_lat = 2.3f * c.S; k.t_load = (c.S <= 3 ? 3.3f : 2.3f) * c.S;
+    k.t_lat = 2.3f * c.S + 0.2f; k.t_load = (c.S <= 3 ? 3.3f : 2.3f) * c.S + 0.2f;
     k.capacity = num_cus * (c.S <= 3 ? 8 : 4) * (64 / c.G);
     return k;
 }
@@ -754,12 +755,12 @@ hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool fo
     if (have16) {
         KernelChoice k;
         k.kind = 1; k.G = G16; k.S = 2 * P16;
-        k.t_lat = 3.5f * P16; k.t_load = 5.0f * P16;
+        k.t_lat = 2.0f * P16 + 2.0f; k.t_load = 5.0f * P16;
         k.capacity = L.num_cus * 8 * (64 / G16);
         L.cand[L.ncand++] = k;
         if (GL16 && !force16) {
             k.G = GL16; k.S = 2 * PL16;
-            k.t_lat = 3.5f * PL16; k.t_load = 5.0f * PL16;
+            k.t_lat = 2.0f * PL16 + 2.0f; k.t_load = 5.0f * PL16;
             k.capacity = L.num_cus * 8 * (64 / GL16);
             L.cand[L.ncand++] = k;
         }

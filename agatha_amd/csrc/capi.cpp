@@ -149,6 +149,8 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     // only candidate (A/B runs, tests).
     { const char* e = getenv("AGATHA_AMD_NO_INT16");
       const char* f = getenv("AGATHA_AMD_FORCE_INT16");
+      const char* c = getenv("AGATHA_AMD_FORCE_CHOICE");
+      L.force_choice = c ? atoi(c) : -1;
       L.choice = choice; L.totals = totals;
       HIPCHK(agatha::plan_align(L, (int)window, e && atoi(e), f && atoi(f))); }
     g_last16 = (L.ncand > 0 && L.cand[0].kind == 1) ? ((L.cand[0].G << 8) | L.cand[0].S) : 0;
