@@ -565,6 +565,9 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                     for (int m = 0; m < 8; m++) { H[p][m] = bfi(RSm, pk2(ha[m], hb[m]), H[p][m]); F[p][m] = bfi(RSm, pk2(fa[m], fb[m]), F[p][m]); }
                     CORNER[p] = bfi(RSm, pk2(ca, cbv), CORNER[p]);
                 }
+                // the reference words requested before the block have long arrived: consume them here, so that no later
+                // register reuse has to wait for them together with the younger loads below
+                asm volatile("" : : "v"(rwa), "v"(rwb));
                 if (__any(ADm != 0u)) {
                     if (ADm & 1u) build_profile5(prof0 + (2 * p) * (4 * 64), rwa, plut);
                     if (ADm >> 31) build_profile5(prof0 + (2 * p + 1) * (4 * 64), rwb, plut);
