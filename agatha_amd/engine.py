@@ -174,6 +174,22 @@ class DeviceBatch:
         for d, h in zip(bufs, self.host):
             _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, d.ptr, h.ctypes.data, h.nbytes))
 
+    def upload_packed(self, packed_q, packed_t, stream=None):
+        """Pre-packed input (the reference's `isPacked` batches, ctors.cpp:65-73): 4-bit codes, 8 bases per uint32, first
+        base in bits 31-28, every sequence starting at word offset byte_offset / 8.  Skips the unpacked upload and the
+        pack kernel; reverse/complement ops are not available on such a batch (they work on the unpacked bytes)."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        pq = np.ascontiguousarray(packed_q, np.uint32)
+        pt = np.ascontiguousarray(packed_t, np.uint32)
+        if pq.size * 8 != self.qbytes or pt.size * 8 != self.tbytes:
+            raise AgathaError("packed batches must hold one uint32 per 8 bytes of the unpacked batch layout")
+        self._packed_host = (pq, pt)          # keep alive until the copies have run
+        _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, self.d_pk_q.ptr, pq.ctypes.data, pq.nbytes))
+        _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, self.d_pk_t.ptr, pt.ctypes.data, pt.nbytes))
+        for d, h in zip(self.d_meta, self.host[2:]):
+            _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, d.ptr, h.ctypes.data, h.nbytes))
+
     def pack(self, stream=None):
         lib = self.eng.lib
         st = stream if stream is not None else self.eng.stream

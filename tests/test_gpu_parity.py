@@ -182,3 +182,24 @@ def test_letters_outside_acgtn(eng):
         got = _gpu(eng, qs2, ts2, p)
         exp = O.align_pairs(qs2, ts2, O.make_params(**p), wide=True, threads=4)
         assert all((a == b).all() for a, b in zip(got, exp)), p
+
+
+def test_prepacked_input(eng):
+    """The reference's `isPacked` data format (ctors.cpp:65-73): the caller ships 4-bit packed words, no pack kernel runs.
+    Packed here on the host by the oracle's restatement of gasal_pack_kernel."""
+    import agatha_amd
+    qs, ts = synth.make_pairs(11, 300, lambda r: int(r.integers(1, 5000)), 0.03, 0.03, 0.04, n_rate=0.01)
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=8)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload_packed(O.pack(qb), O.pack(tb))
+        b.align(agatha_amd.Scores.make(**p))
+        b.download()
+        eng.synchronize()
+        for k in range(3):
+            assert np.array_equal(b.res_host[k], exp[k])
+    finally:
+        b.free()
