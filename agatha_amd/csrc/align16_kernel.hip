@@ -407,11 +407,16 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                 const uint32_t UPm = eq_mask(pk_add(q2, W2), rc, ONE2) & ACTm, LOm = eq_mask(q2, pk_add(rc, W2), ONE2) & ACTm;
                 uint32_t UP2m = 0u, LO2m = 0u;
                 if (CORNER_BLOCKS) {
-                    UP2m = eq_mask(q2, 0u, ONE2) & eq_mask(rc, dup2((uint32_t)(W - 1)), ONE2) & ACTm;
-                    LO2m = eq_mask(q2, PQL1, ONE2) & eq_mask(pk_add(q2, ONE2), pk_add(rc, W2), ONE2) & ACTm;
+                    // E cut on T0 + 8: block (0, W-1), and the block of the LAST row block with r - q = W - 1 (a boundary block
+                    // because its column ends there, although the cut is on its upper side)
+                    const uint32_t lastq = eq_mask(q2, PQL1, ONE2);
+                    UP2m = ((eq_mask(q2, 0u, ONE2) & eq_mask(rc, dup2((uint32_t)(W - 1)), ONE2)) |
+                            (lastq & eq_mask(pk_add(q2, dup2((uint32_t)(W - 1))), rc, ONE2))) & ACTm;
+                    LO2m = lastq & eq_mask(pk_add(q2, ONE2), pk_add(rc, W2), ONE2) & ACTm;
                 }
-                {
-                    // safety net: a boundary block with a cut that is none of the kinds above must not be computed here
+                if (CORNER_BLOCKS) {
+                    // safety net (only where the classification above has more than two kinds): a boundary block with a cut
+                    // that is none of them must not be computed here
                     const uint32_t bnd = (eq_mask(q2, cs2, ONE2) | eq_mask(q2, ce2, ONE2)) & ACTm & ~(UPm | LOm | UP2m | LO2m);
                     if (__builtin_expect(bnd != 0u, 0)) {
                         const int qa_ = i - ra, qb_ = i - rb;
@@ -513,6 +518,14 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                     if (jl < -t0) F[p][jl] = bfi(LOm, OUT2, F[p][jl]);
                     if (jl >= 1 && jl < -t0) H[p][jl - 1] = bfi(LOm, OUT2, H[p][jl - 1]);
                 }
+                // blocks cut on T0 + 8 that are not the first row block of their column (the last row block): cells (0, jl)
+                // with jl > T0 + 8 are outside (for block (0, W-1) the initial column state already says so)
+                if (CORNER_BLOCKS) {
+#pragma unroll
+                    for (int jl = 1; jl < 8; jl++) {
+                        if (jl > t0 + 8) { F[p][jl] = bfi(UP2m, OUT2, F[p][jl]); H[p][jl - 1] = bfi(UP2m, OUT2, H[p][jl - 1]); }
+                    }
+                }
 
                 // ---- what E and F lose per step on the cut diagonals ----
                 const uint32_t gcu = bfi(UPm, CUT2, GE2), gcl = bfi(LOm, CUT2, GE2);
@@ -577,11 +590,12 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                 // later (raw: converting them here would wait for the load)
                 {
                     const uint32_t rcn = RC[p];
-                    const int qna = i + 1 - (int)(rcn & 0xffffu), qnb = i + 1 - (int)(rcn >> 16);
-                    uint32_t qva = 0u, qvb = 0u;
-                    if (alive && qna >= 0 && qna < pql) qva = ((gptr_t)La->packed_q)[pq + (uint32_t)qna];
-                    if (alive && qnb >= 0 && qnb < pql) qvb = ((gptr_t)La->packed_q)[pq + (uint32_t)qnb];
-                    qcls[2 * p] = qva; qcls[2 * p + 1] = qvb;
+                    // A half whose row block does not exist (yet) is inactive in that step and computes on garbage anyway, so
+                    // the address is only clamped into the pair's query (no branch, no select on the loaded word).
+                    const int qhi = imax(pql - 1, 0);
+                    const int qna = imin(imax(i + 1 - (int)(rcn & 0xffffu), 0), qhi), qnb = imin(imax(i + 1 - (int)(rcn >> 16), 0), qhi);
+                    qcls[2 * p] = ((gptr_t)La->packed_q)[pq + (uint32_t)qna];
+                    qcls[2 * p + 1] = ((gptr_t)La->packed_q)[pq + (uint32_t)qnb];
                 }
             }
         }
@@ -630,10 +644,19 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
             calm = calm && lo_rep >= bail_rep && lo_abs >= NEG_INF2 + spread && (z < 0 || imax(best, hi_abs) - lo_abs <= z);
         }
         if (__builtin_expect(__all(calm || !alive), 1)) {
+            // only the running maximum moves: the anti-diagonal with the largest H wins, the earliest one among equals
+            // (the reference walks them in order and updates on H > max only); one max over H : 7 - x : column
+            static_assert(K + 3 + 16 <= 32, "key of the fast path");
+            uint32_t mk = 0u;
 #pragma unroll
             for (int x = 0; x < 8; x++) {
-                const int Hv = (vred[x] >> K) - r16::BIAS + base;
-                if (alive && Hv > best) { best = Hv; best_t = (vred[x] & KMASK) + cb; best_q = 8 * i + x - best_t; }
+                const uint32_t v = (uint32_t)vred[x];
+                const uint32_t k3 = ((v & ~(uint32_t)KMASK) << 3) | ((uint32_t)(7 - x) << K) | (v & (uint32_t)KMASK);
+                mk = k3 > mk ? k3 : mk;
+            }
+            const int Hm = (int)(mk >> (K + 3)) - r16::BIAS + base;
+            if (alive && Hm > best) {
+                best = Hm; best_t = (int)(mk & (uint32_t)KMASK) + cb; best_q = 8 * i + 7 - (int)((mk >> K) & 7u) - best_t;
             }
         } else {
 #pragma unroll

@@ -52,6 +52,22 @@ def _run(eng, qs, ts, p):
     return got, exp
 
 
+def _run_with_kinds(eng, qs, ts, p):
+    """Like _run, plus how the pairs were routed (plain, other letters, taken over by the int32 kernel)."""
+    import agatha_amd
+    qb, qo, ql = WL.make_batch(qs)
+    tb, to, tl = WL.make_batch(ts)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=8)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
+        got = tuple(b.res_host[k].copy() for k in range(3))
+        kinds = b.pair_kinds()
+    finally:
+        b.free()
+    return got, exp, kinds
+
+
 def _same(got, exp):
     return all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got, exp))
 
@@ -87,18 +103,26 @@ def test_int16_kernel_matches_oracle(eng, p):
 @pytest.mark.parametrize("w", list(range(745, 753)) + [97, 250, 505])
 def test_every_cut_diagonal(eng, w):
     """w mod 8 decides which cell diagonal of an edge block is cut (one compiled kernel per value), and for w mod 8 in
-    1..6 the two blocks next to the corners of the band are cut as well."""
+    1..6 the blocks next to the corners of the band are cut as well."""
     p = dict(BASE, w=w, s=int(1 + w % 3))
     qs, ts = WL.cfg_c4(n=128, seed=1000 + w, lo=30, hi=12000)
+    got, exp, kinds = _run_with_kinds(eng, qs, ts, p)
+    assert _same(got, exp)
+    assert eng.last_int16_config() == _expected_int16_config(p)
+    # z-drop is on and no sequence holds an N: the int16 kernel must finish every one of these pairs itself (a hand-back
+    # would hide a block the kernel cannot classify behind the int32 kernel's correct answer)
+    assert kinds == (len(qs), 0, 0)
+    # matrices around the band's corners, and pairs whose band leaves the matrix through its side (these may be handed
+    # back: anti-diagonals on which only padded columns remain)
     rng = np.random.default_rng(w)
-    for L in (7, 8, 9, 8 * ((w + 7) // 8) - 1, 8 * ((w + 7) // 8) + 1, w, w + 1, 2 * w, 2 * w + 9):     # matrices around the band's corners
+    qs, ts = [], []
+    for L in (7, 8, 9, 8 * ((w + 7) // 8) - 1, 8 * ((w + 7) // 8) + 1, w, w + 1, 2 * w, 2 * w + 9):
         a = WL.random_seq(rng, L)
         qs.append(a.tobytes()); ts.append(WL.mutate(rng, a, 0.02, 0.02, 0.02).tobytes() or b"A")
         qs.append(a.tobytes()); ts.append(np.concatenate([a, WL.random_seq(rng, w + 40)]).tobytes())
         qs.append(np.concatenate([a, WL.random_seq(rng, w + 40)]).tobytes()); ts.append(a.tobytes())
     got, exp = _run(eng, qs, ts, p)
     assert _same(got, exp)
-    assert eng.last_int16_config() == _expected_int16_config(p)
 
 
 def test_int16_and_int32_kernels_agree(eng):
