@@ -19,7 +19,9 @@
 //   * a pair whose anti-diagonal maximum comes too close to the zone borders (an in-band cell could leave its zone, or
 //     the exact value of -infinity could start to matter) is abandoned and flagged for the int32 kernel.
 // The kernel is compiled per cut diagonal T0 = w - 8*ceil(w/8) (0..-7), so which cells carry a cut operand is known at
-// compile time; the launcher uses it when the scores pass agatha16_scores_ok() and a (G, P) exists for the window.
+// compile time (for T0 < -1 three more block kinds per pair are cut, on T0 + 8).  The launcher offers it as a candidate
+// when the scores pass agatha16_scores_ok() and a (G, P) exists for the window; record_kernel (align_kernel.hip) picks
+// the candidate that runs from the batch's length histogram.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
