@@ -11,7 +11,7 @@ a=s.index('static const Cfg kCfgs[] = {'); b=s.index('};',a)
 s=s[:a]+'static const Cfg kCfgs[] = {\n    {%s, %s, launch_align_t<%s, %s>},\n'%(G,S,G,S)+s[b:]
 open('/tmp/isa/one.hip','w').write(s)
 PY
-cp kernels.h /tmp/isa/
+cp kernels.h device_common.h /tmp/isa/
 FLAGS=$(grep '^CXXFLAGS' Makefile | sed 's/CXXFLAGS *= *//; s/\$(ARCH)/gfx950/')
 hipcc $FLAGS -S --cuda-device-only -o /tmp/isa/one.s /tmp/isa/one.hip -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A9 "align_kernel" | grep -E "error|VGPRs:|SGPRs:|Spill|Occupancy|Scratch"
 python3 isa_stats.py /tmp/isa/one.s $G,$S
