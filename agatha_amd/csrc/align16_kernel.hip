@@ -5,13 +5,20 @@
 // (high half) of a 32-bit register, v_pk_* arithmetic, i.e. two DP cells per VALU lane-op.  What makes that possible
 // and bit-exact (each point is emulated and checked against the oracle in oracle/agatha_lanes_model.c,
 // agatha_model_lanes16):
-//   * values are an unsigned 16-bit REPRESENTATION rep = value - base + 32768; `base` follows the running maximum of
-//     the pair, so sequence length does not limit the domain.  Three disjoint zones: in-band cells >= R_LO, the
-//     reference's -infinity and what derives from it in [R_GLO, R_LO), cells outside the band below R_GLO.
+//   * values are an unsigned 16-bit REPRESENTATION in a DRIFTING FRAME: rep = value + ge * (row + column) - base + 32768,
+//     i.e. every quantity of cell (row, column) -- its H, the E and F that enter it -- is seen from its own
+//     anti-diagonal.  A gap extension then costs nothing (E' = max(t - gap_open, E), F likewise: five packed instructions
+//     per cell pair instead of seven), the two anti-diagonals between a cell and its diagonal neighbour are a constant
+//     + 2 ge inside the score profile, every boundary value of the first band width is a constant, and an anti-diagonal
+//     maximum can hardly sink in this frame (it loses at most ge per anti-diagonal in value).  `base` is raised whenever
+//     the representation of a maximum passes R_REBASE, so sequence length does not limit the domain; maxima are moved
+//     back to values where they are compared across anti-diagonals (z-drop, running maximum).  Three disjoint zones:
+//     in-band cells >= R_LO, the reference's -infinity and what derives from it in [R_GLO, R_LO), cells outside the band
+//     below R_GLO.
 //   * no per-cell band test (an EXEC mask cannot switch off half a register): every cell of an active block is computed,
-//     and the band is cut by subtracting R_CUT instead of the gap-extension score on ONE cell diagonal -- E leaving the
-//     band to the right in upper-edge blocks, F leaving it downwards in lower-edge blocks -- plus R_OUT on what
-//     enters an out-of-band cell from a neighbouring block.  Out-of-band cells then only hold values below R_GLO, lose
+//     and the band is cut by capping E (upper-edge blocks: leaving the band to the right) or F (lower-edge blocks:
+//     leaving it downwards) at R_OUT on ONE cell diagonal -- one extra v_pk_min on those eight cells -- plus R_OUT on
+//     what enters an out-of-band cell from a neighbouring block.  Out-of-band cells then only hold values below R_GLO, lose
 //     every max against an in-band value, and an anti-diagonal whose maximum is below R_GLO is empty, as in the
 //     reference.  Lower-edge blocks hand on the reference's stale row values (agatha_kernel.h:33 skips, it does not
 //     reset).  Rows past the end of the query and inactive halves are kept out of the maxima by a zero multiplier in
@@ -34,10 +41,9 @@ namespace agatha {
 namespace r16 {
 constexpr int BIAS = 32768;
 constexpr int LO = -13000 + BIAS;        // in-band values are >= LO (bail-out rule)
-constexpr int NEG = -13800 + BIAS;       // the reference's -infinity
-constexpr int GLO = -14400 + BIAS;       // below: out-of-band cells / nothing
-constexpr int OUT = -30000 + BIAS;       // state entering an out-of-band cell
-constexpr int CUT = 17408;               // subtracted where E / F leave the band
+constexpr int NEG = -17500 + BIAS;       // the reference's -infinity
+constexpr int GLO = -22000 + BIAS;       // below: out-of-band cells / nothing
+constexpr int OUT = -28000 + BIAS;       // state entering an out-of-band cell; E / F where they leave the band
 constexpr int REBASE = 2048 + BIAS;      // rebase when an anti-diagonal maximum exceeds this
 constexpr int DELTA = 2048;
 }  // namespace r16
@@ -79,15 +85,15 @@ __device__ __forceinline__ void init_half(int r, int R, int w, int W, int gapoe,
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         const int c = 8 * r + m;
-        const int k = -(gapoe + ge * c) - base;
         const bool in = (c < R) && (c <= w);
-        uint32_t h = in ? rep16(k) : (uint32_t)r16::NEG;
-        uint32_t f = in ? rep16(k - gapoe) : (uint32_t)r16::NEG;
+        // H(-1, c) = -(gapoe + ge c) seen from anti-diagonal c - 1, F(0, c) = that - gapoe seen from anti-diagonal c
+        uint32_t h = in ? rep16(-(gapoe + ge) - base) : (uint32_t)r16::NEG;
+        uint32_t f = in ? rep16(-2 * gapoe - base) : (uint32_t)r16::NEG;
         if (m > tu0) f = r16::OUT;                       // cell (0, m) of the first block is outside the band
         if (m < 7 && m + 1 > tu0) h = r16::OUT;          // so is the cell this value is the diagonal of
         hv[m] = h; fv[m] = f;
     }
-    uint32_t c0 = (r == 0) ? rep16(0 - base) : ((8 * r - 1) <= w ? rep16(-(gapoe + ge * (8 * r - 1)) - base) : (uint32_t)r16::NEG);
+    uint32_t c0 = (r == 0) ? rep16(-2 * ge - base) : ((8 * r - 1) <= w ? rep16(-(gapoe + ge) - base) : (uint32_t)r16::NEG);
     if (0 > tu0) c0 = r16::OUT;
     cv = c0;
 }
@@ -97,11 +103,12 @@ __device__ __forceinline__ void init_half(int r, int R, int w, int W, int gapoe,
 // base (A 0, C 1, T 2, G 3, N 7) selects a byte of an 8-entry table {match at the query's own class, -mismatch
 // elsewhere, -1 for N}.  lut_hi = entries 4..7, lut[c] = entries 0..3 of query class c.
 struct ProfileLut { uint32_t hi, lo[4]; };
-__device__ __forceinline__ ProfileLut make_profile_lut(int a, int b)
+__device__ __forceinline__ ProfileLut make_profile_lut(int a, int b, int ge)
 {
     ProfileLut t;
-    const uint32_t nb = (uint32_t)(-b) & 0xFFu, ma = (uint32_t)a & 0xFFu;
-    t.hi = 0xFF000000u | (nb * 0x00010101u);
+    // every score carries the + 2 ge of the two anti-diagonals between a cell and its diagonal neighbour (see rep above)
+    const uint32_t nb = (uint32_t)(2 * ge - b) & 0xFFu, ma = (uint32_t)(2 * ge + a) & 0xFFu, nn = (uint32_t)(2 * ge - 1) & 0xFFu;
+    t.hi = (nn << 24) | (nb * 0x00010101u);
 #pragma unroll
     for (int c = 0; c < 4; c++) t.lo[c] = ((nb * 0x01010101u) & ~(0xFFu << (8 * c))) | (ma << (8 * c));
     return t;
@@ -152,28 +159,32 @@ __device__ __forceinline__ void row_add_scores(uint32_t (&h)[8], uint32_t d0, ui
 }
 
 // four cells of a row: t comes in as diagonal + score and leaves as the new H; F of the four columns and the row's E are
-// advanced (gap-extension operands gf*, ge* per cell: the gap-extension score, or R_CUT on a cut diagonal)
+// advanced.  In the drifting frame neither loses the gap-extension score (see rep above): five instructions per cell
+// pair.  MF / ME: two bits per cell, 1 = F / E of that cell leaves the band on the block kind's first cut diagonal (operand
+// ca: R_OUT in the halves of that kind, 0xFFFF elsewhere), 2 = on its second one (operand cb); the assembler drops the rest.
+template <int MF, int ME>
 __device__ __forceinline__ void row_cells4(uint32_t& t0, uint32_t& t1, uint32_t& t2, uint32_t& t3, uint32_t& f0, uint32_t& f1,
-                                           uint32_t& f2, uint32_t& f3, uint32_t& ev, uint32_t gapo, uint32_t gf0, uint32_t gf1,
-                                           uint32_t gf2, uint32_t gf3, uint32_t ge0, uint32_t ge1, uint32_t ge2_, uint32_t ge3)
+                                           uint32_t& f2, uint32_t& f3, uint32_t& ev, uint32_t gapo, uint32_t fa, uint32_t fb,
+                                           uint32_t ea, uint32_t eb)
 {
     uint32_t x, u;
-#define AGATHA16_CELL(T, F, GF, GE) \
+#define AGATHA16_CELL(T, F, J) \
         "v_pk_max_u16 %[x], " T ", " F "\n\t" \
         "v_pk_sub_u16 %[u], " T ", %[gapo]\n\t" \
         "v_pk_max_u16 " T ", %[x], %[ev]\n\t" \
         "v_pk_max_u16 " F ", %[u], " F "\n\t" \
         "v_pk_max_u16 %[ev], %[u], %[ev]\n\t" \
-        "v_pk_sub_u16 " F ", " F ", " GF "\n\t" \
-        "v_pk_sub_u16 %[ev], %[ev], " GE "\n\t"
-    asm(AGATHA16_CELL("%[t0]", "%[f0]", "%[gf0]", "%[ge0]")
-        AGATHA16_CELL("%[t1]", "%[f1]", "%[gf1]", "%[ge1]")
-        AGATHA16_CELL("%[t2]", "%[f2]", "%[gf2]", "%[ge2]")
-        AGATHA16_CELL("%[t3]", "%[f3]", "%[gf3]", "%[ge3]")
+        ".if ((%[mf] >> (2 * " J ")) & 3) == 1\n\tv_pk_min_u16 " F ", " F ", %[fa]\n\t.endif\n\t" \
+        ".if ((%[mf] >> (2 * " J ")) & 3) == 2\n\tv_pk_min_u16 " F ", " F ", %[fb]\n\t.endif\n\t" \
+        ".if ((%[me] >> (2 * " J ")) & 3) == 1\n\tv_pk_min_u16 %[ev], %[ev], %[ea]\n\t.endif\n\t" \
+        ".if ((%[me] >> (2 * " J ")) & 3) == 2\n\tv_pk_min_u16 %[ev], %[ev], %[eb]\n\t.endif\n\t"
+    asm(AGATHA16_CELL("%[t0]", "%[f0]", "0")
+        AGATHA16_CELL("%[t1]", "%[f1]", "1")
+        AGATHA16_CELL("%[t2]", "%[f2]", "2")
+        AGATHA16_CELL("%[t3]", "%[f3]", "3")
         : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [f0] "+v"(f0), [f1] "+v"(f1), [f2] "+v"(f2), [f3] "+v"(f3),
           [ev] "+v"(ev), [x] "=&v"(x), [u] "=&v"(u)
-        : [gapo] "s"(gapo), [gf0] "v"(gf0), [gf1] "v"(gf1), [gf2] "v"(gf2), [gf3] "v"(gf3), [ge0] "v"(ge0), [ge1] "v"(ge1),
-          [ge2] "v"(ge2_), [ge3] "v"(ge3));
+        : [gapo] "s"(gapo), [fa] "v"(fa), [fb] "v"(fb), [ea] "v"(ea), [eb] "v"(eb), [mf] "i"(MF), [me] "i"(ME));
 #undef AGATHA16_CELL
 }
 
@@ -207,37 +218,62 @@ __device__ __forceinline__ uint2 profile_row(const uint2* __restrict__ p, uint32
     return p[c * 64u];
 }
 
+// which cut a cell's E (jl - il) / F (il - jl) carries in a block pair compiled for cut diagonal T0: 1 on T0, 2 on T0 + 8
+template <int T0>
+constexpr int cut_code(int d)
+{
+    return d == T0 ? 1 : ((T0 + 8 < 7) && d == T0 + 8) ? 2 : 0;
+}
+template <int T0>
+constexpr int cut_mask4(int il, int j0, bool for_e)
+{
+    int m = 0;
+    for (int j = 0; j < 4; j++) m |= cut_code<T0>(for_e ? (j0 + j) - il : il - (j0 + j)) << (2 * j);
+    return m;
+}
+
+struct BlockOps {
+    uint32_t gapo2, cu, cu2, cl, cl2, NRK, qc_lo, qc_hi;
+    int crel_lo, crel_hi;
+    const uint2* pl; const uint2* ph;
+};
+
+// one row of a block pair.  wl / wh: the row's profile words (requested a row ahead)
+template <int K, int T0, int IL>
+__device__ __forceinline__ void block_row16(uint32_t (&h)[8], uint32_t (&f)[8], uint32_t d0, uint32_t (&e)[8], uint32_t (&oh)[8],
+                                            int (&A)[15], const BlockOps& o, uint2& wl, uint2& wh)
+{
+    // key multiplier of this row: 2^K where the row exists (IL < rows), 0 where it does not
+    const uint32_t kmul = pk_min_c(pk_sub_sat_c(o.NRK, dup2((uint32_t)(IL << K))), dup2(1u << K));
+    row_add_scores(h, d0, wl, wh);
+    if (IL < 7) {
+        wl = profile_row(o.pl, o.qc_lo, 24 - 4 * IL);
+        wh = profile_row(o.ph, o.qc_hi, 24 - 4 * IL);
+    }
+    uint32_t ev = e[IL];
+    // E is cut on cell diagonal jl - il == T0 (upper edge blocks) or T0 + 8 (the block next to the corner of the band),
+    // F on il - jl == T0 or T0 + 8 (lower edge blocks)
+    row_cells4<cut_mask4<T0>(IL, 0, false), cut_mask4<T0>(IL, 0, true)>(h[0], h[1], h[2], h[3], f[0], f[1], f[2], f[3], ev, o.gapo2, o.cl, o.cl2, o.cu, o.cu2);
+    row_cells4<cut_mask4<T0>(IL, 4, false), cut_mask4<T0>(IL, 4, true)>(h[4], h[5], h[6], h[7], f[4], f[5], f[6], f[7], ev, o.gapo2, o.cl, o.cl2, o.cu, o.cu2);
+    row_keys4(A[IL], A[IL + 1], A[IL + 2], A[IL + 3], h[0], h[1], h[2], h[3], kmul, o.crel_lo - IL, o.crel_hi - IL);
+    row_keys4(A[IL + 4], A[IL + 5], A[IL + 6], A[IL + 7], h[4], h[5], h[6], h[7], kmul, o.crel_lo - IL, o.crel_hi - IL);
+    oh[IL] = h[7]; e[IL] = ev;
+}
+
 template <int K, int T0>
 __device__ __forceinline__ void block_pair16(uint32_t (&h)[8], uint32_t (&f)[8], uint32_t corner, const uint32_t (&rh)[8],
-                                             uint32_t (&e)[8], uint32_t (&oh)[8], int (&A)[15], uint32_t qc_lo, uint32_t qc_hi,
-                                             const uint2* __restrict__ pl, const uint2* __restrict__ ph, uint32_t gapo2,
-                                             uint32_t ge2, uint32_t gcu, uint32_t gcu2, uint32_t gcl, uint32_t gcl2, uint32_t NRK,
-                                             int crel_lo, int crel_hi)
+                                             uint32_t (&e)[8], uint32_t (&oh)[8], int (&A)[15], const BlockOps& o)
 {
     // profile rows are requested while the previous row's cells are being computed
-    uint2 wl = profile_row(pl, qc_lo, 28), wh = profile_row(ph, qc_hi, 28);
-#pragma unroll
-    for (int il = 0; il < 8; il++) {
-        // key multiplier of this row: 2^K where the row exists (il < rows), 0 where it does not
-        const uint32_t kmul = pk_min_c(pk_sub_sat_c(NRK, dup2((uint32_t)(il << K))), dup2(1u << K));
-        row_add_scores(h, il == 0 ? corner : rh[il > 0 ? il - 1 : 0], wl, wh);
-        if (il < 7) {
-            wl = profile_row(pl, qc_lo, 24 - 4 * il);
-            wh = profile_row(ph, qc_hi, 24 - 4 * il);
-        }
-        uint32_t ev = e[il];
-        // per-cell gap-extension operands: E is cut on cell diagonal jl - il == T0 (upper edge blocks) or T0 + 8 (the
-        // block next to the corner of the band), F on -T0 or -(T0 + 8) (lower edge blocks); everywhere else plain ge
-#define GE_E(jl) ((jl) - il == T0 ? gcu : (jl) - il == T0 + 8 ? gcu2 : ge2)
-#define GE_F(jl) ((jl) - il == -T0 ? gcl : (jl) - il == -(T0 + 8) ? gcl2 : ge2)
-        row_cells4(h[0], h[1], h[2], h[3], f[0], f[1], f[2], f[3], ev, gapo2, GE_F(0), GE_F(1), GE_F(2), GE_F(3), GE_E(0), GE_E(1), GE_E(2), GE_E(3));
-        row_cells4(h[4], h[5], h[6], h[7], f[4], f[5], f[6], f[7], ev, gapo2, GE_F(4), GE_F(5), GE_F(6), GE_F(7), GE_E(4), GE_E(5), GE_E(6), GE_E(7));
-#undef GE_E
-#undef GE_F
-        row_keys4(A[il], A[il + 1], A[il + 2], A[il + 3], h[0], h[1], h[2], h[3], kmul, crel_lo - il, crel_hi - il);
-        row_keys4(A[il + 4], A[il + 5], A[il + 6], A[il + 7], h[4], h[5], h[6], h[7], kmul, crel_lo - il, crel_hi - il);
-        oh[il] = h[7]; e[il] = ev;
-    }
+    uint2 wl = profile_row(o.pl, o.qc_lo, 28), wh = profile_row(o.ph, o.qc_hi, 28);
+    block_row16<K, T0, 0>(h, f, corner, e, oh, A, o, wl, wh);
+    block_row16<K, T0, 1>(h, f, rh[0], e, oh, A, o, wl, wh);
+    block_row16<K, T0, 2>(h, f, rh[1], e, oh, A, o, wl, wh);
+    block_row16<K, T0, 3>(h, f, rh[2], e, oh, A, o, wl, wh);
+    block_row16<K, T0, 4>(h, f, rh[3], e, oh, A, o, wl, wh);
+    block_row16<K, T0, 5>(h, f, rh[4], e, oh, A, o, wl, wh);
+    block_row16<K, T0, 6>(h, f, rh[5], e, oh, A, o, wl, wh);
+    block_row16<K, T0, 7>(h, f, rh[6], e, oh, A, o, wl, wh);
 }
 
 // ---- packed per-half control arithmetic: column indices, row-block indices and tags are 16-bit (sequences shorter
@@ -282,11 +318,13 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
         int per = 2 * ge; if (Pm.mismatch > per) per = Pm.mismatch; if (per < 1) per = 1;
         spread = gapoe + per * (w + 16) + 64;
     }
-    const int bail_rep = r16::LO + spread + r16::DELTA;
-    const uint32_t GAPO2 = dup2((uint32_t)gapo), GE2 = dup2((uint32_t)ge), CUT2 = dup2(r16::CUT);
+    // (+ 7 ge: the maxima of a step's eight anti-diagonals are compared after moving them to the frame of the first)
+    const int bail_rep = r16::LO + spread + r16::DELTA + 7 * ge;
+    const int frame_mul = 1 - (ge << K);           // A[x] + x * frame_mul: column + x, H field - ge * x
+    const uint32_t GAPO2 = dup2((uint32_t)gapo);
     const uint32_t NEG2 = dup2(r16::NEG), OUT2 = dup2(r16::OUT), ONE2 = 0x00010001u, K2 = dup2(K), F15 = 0x000F000Fu;
     const uint32_t W2 = dup2((uint32_t)W), NOTAG = 0xFFFEFFFEu;
-    const ProfileLut plut = make_profile_lut(Pm.match, Pm.mismatch);
+    const ProfileLut plut = make_profile_lut(Pm.match, Pm.mismatch, ge);
     // initial state of a column block beyond the first band width (init_half with r > W): constants per column
     const uint32_t HINIT = OUT2, H7INIT = NEG2;     // h[m], m < 7: the cell it is the diagonal of, (0, m+1), is outside for t0 <= 0
     const uint32_t F0INIT = (0 > t0) ? OUT2 : NEG2, FINIT = OUT2, CINIT = (0 > t0) ? OUT2 : NEG2;
@@ -475,9 +513,10 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
 #pragma unroll
                     for (int il = 0; il < 8; il++) {
                         const int rowa = 8 * qa + il, rowb = 8 * qb + il;
-                        const int ka = -(gapoe + ge * rowa) - base, kb = -(gapoe + ge * rowb) - base;
-                        uint32_t iha = (rowa <= w) ? rep16(ka) : (uint32_t)r16::NEG, iea = (rowa <= w) ? rep16(ka - gapoe) : (uint32_t)r16::NEG;
-                        uint32_t ihb = (rowb <= w) ? rep16(kb) : (uint32_t)r16::NEG, ieb = (rowb <= w) ? rep16(kb - gapoe) : (uint32_t)r16::NEG;
+                        // H(row, -1) = -(gapoe + ge row) seen from anti-diagonal row - 1, E(row, 0) = that - gapoe seen from row
+                        const uint32_t hb_ = rep16(-(gapoe + ge) - base), eb_ = rep16(-2 * gapoe - base);
+                        uint32_t iha = (rowa <= w) ? hb_ : (uint32_t)r16::NEG, iea = (rowa <= w) ? eb_ : (uint32_t)r16::NEG;
+                        uint32_t ihb = (rowb <= w) ? hb_ : (uint32_t)r16::NEG, ieb = (rowb <= w) ? eb_ : (uint32_t)r16::NEG;
                         uint32_t vha = oka ? (XH[p][il] & 0xffffu) : iha, vea = oka ? (xin[il] & 0xffffu) : iea;
                         uint32_t vhb = okb ? (XH[p][il] >> 16) : ihb, veb = okb ? (xin[il] >> 16) : ieb;
                         // cell (il, 0) outside the band: its E is R_OUT; cell (il + 1, 0) outside: its diagonal (this H) is
@@ -529,20 +568,27 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                     }
                 }
 
-                // ---- what E and F lose per step on the cut diagonals ----
-                const uint32_t gcu = bfi(UPm, CUT2, GE2), gcl = bfi(LOm, CUT2, GE2);
-                const uint32_t gcu2 = CORNER_BLOCKS ? bfi(UP2m, CUT2, GE2) : GE2, gcl2 = CORNER_BLOCKS ? bfi(LO2m, CUT2, GE2) : GE2;
+                // ---- upper bounds of E and F on the cut diagonals: R_OUT in the halves of that block kind ----
+                const uint32_t gcu = OUT2 | ~UPm, gcl = OUT2 | ~LOm;
+                const uint32_t gcu2 = CORNER_BLOCKS ? (OUT2 | ~UP2m) : gcu, gcl2 = CORNER_BLOCKS ? (OUT2 | ~LO2m) : gcl;
                 // rows that exist: 8, fewer in the last row block, 0 for an inactive half
                 const uint32_t NR = bfi(eq_mask(q2, PQL1, ONE2), NRLAST, 0x00080008u) & ACTm;
 
-                block_pair16<K, T0>(H[p], F[p], corner_in, rh, e, XH[p], A, class_word(qcls[2 * p]), class_word(qcls[2 * p + 1]), prof0 + (2 * p) * (4 * 64),
-                                    prof0 + (2 * p + 1) * (4 * 64), GAPO2, GE2, gcu, gcu2, gcl, gcl2, pk_shl_c(NR, K2), 8 * ra - cb, 8 * rb - cb);
+                {
+                    BlockOps o;
+                    o.gapo2 = GAPO2; o.cu = gcu; o.cu2 = gcu2; o.cl = gcl; o.cl2 = gcl2; o.NRK = pk_shl_c(NR, K2);
+                    o.qc_lo = class_word(qcls[2 * p]); o.qc_hi = class_word(qcls[2 * p + 1]);
+                    o.crel_lo = 8 * ra - cb; o.crel_hi = 8 * rb - cb;
+                    o.pl = prof0 + (2 * p) * (4 * 64); o.ph = prof0 + (2 * p + 1) * (4 * 64);
+                    block_pair16<K, T0>(H[p], F[p], corner_in, rh, e, XH[p], A, o);
+                }
                 // lower edge blocks: the rows il > 7 + T0 end below the band; they hand on what the reference's skipped cells
                 // leave in its registers: H of row 7 + T0 at column 7, and the incoming E (-infinity)
 #pragma unroll
                 for (int il = 1; il < 8; il++) {
                     if (il > 7 + t0) {
-                        XH[p][il] = bfi(LOm, XH[p][7 + t0], XH[p][il]);
+                        // (the same value, seen from il - (7 + T0) anti-diagonals further on)
+                        XH[p][il] = bfi(LOm, pk_add_c(XH[p][7 + t0], dup2((uint32_t)(ge * (il - 7 - t0)))), XH[p][il]);
                         e[il] = bfi(LOm, NEG2, e[il]);
                     }
                 }
@@ -633,7 +679,8 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
         bool stopped = false;
         int vred[8];
 #pragma unroll
-        for (int x = 0; x < 8; x++) vred[x] = A[x] + x;        // see row_keys4
+        for (int x = 0; x < 8; x++) vred[x] = A[x] + x * frame_mul;        // see row_keys4; H fields now in the frame of 8i
+        const int base_i = base - 8 * ge * i;                               // value = rep - BIAS + base_i there
         group_max8<G>(vred, lane);
         int lo8 = vred[0], hi8 = vred[0];
 #pragma unroll
@@ -642,7 +689,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
         // the pair, and within z of the running maximum, so neither z-drop nor the bail-out can fire.
         bool calm = !final_step && (8 * i + 7 < lim) && !bail;
         {
-            const int lo_rep = lo8 >> K, lo_abs = lo_rep - r16::BIAS + base, hi_abs = (hi8 >> K) - r16::BIAS + base;
+            const int lo_rep = lo8 >> K, lo_abs = lo_rep - r16::BIAS + base_i, hi_abs = (hi8 >> K) - r16::BIAS + base_i;
             calm = calm && lo_rep >= bail_rep && lo_abs >= NEG_INF2 + spread && (z < 0 || imax(best, hi_abs) - lo_abs <= z);
         }
         if (__builtin_expect(__all(calm || !alive), 1)) {
@@ -656,7 +703,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                 const uint32_t k3 = ((v & ~(uint32_t)KMASK) << 3) | ((uint32_t)(7 - x) << K) | (v & (uint32_t)KMASK);
                 mk = k3 > mk ? k3 : mk;
             }
-            const int Hm = (int)(mk >> (K + 3)) - r16::BIAS + base;
+            const int Hm = (int)(mk >> (K + 3)) - r16::BIAS + base_i;
             if (alive && Hm > best) {
                 best = Hm; best_t = (int)(mk & (uint32_t)KMASK) + cb; best_q = 8 * i + 7 - (int)((mk >> K) & 7u) - best_t;
             }
@@ -667,7 +714,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                 const int d = 8 * i + x;
                 const bool chk = alive && !stopped && !bail && (final_step || d < lim);      // agatha_kernel.h:293-294 / 337
                 const int rep = v >> K;
-                int Hv = rep - r16::BIAS + base, c = (v & KMASK) + cb;
+                int Hv = rep - r16::BIAS + base_i, c = (v & KMASK) + cb;
                 if (rep < r16::GLO) { Hv = -32768; c = 0; }                                // empty, or only out-of-band cells
                 else if (chk && (rep < bail_rep || Hv < NEG_INF2 + spread)) bail = true;
                 if (chk && !bail) {                                                        // agatha_kernel.h:297-309

@@ -222,13 +222,17 @@ int agatha_model_lanes(const char *qs, int Q, const char *rs, int R, const lm_pa
  *
  * Same schedule as above; the arithmetic differs in three ways, all of which this model checks against the
  * int32 model on the CPU before the kernel relies on them:
- *   (1) all DP state is an int16 REPRESENTATION rep = value - base.  The base follows the running maximum
- *       (rebased by L16_DELTA whenever an anti-diagonal maximum exceeds L16_REBASE), so sequence length does not
- *       limit the domain.  Three disjoint zones: in-band values live in [L16_LO, ~L16_REBASE + 16*match]; the
- *       reference's -infinity and what is derived from it in [L16_GLO, L16_LO); cells outside the band below L16_GLO.
+ *   (1) all DP state is an int16 REPRESENTATION in a drifting frame: rep = value + ge * (row + column) - base, every
+ *       quantity of a cell seen from the cell's own anti-diagonal.  E and F then carry over unchanged where the value
+ *       loses the gap-extension score (E' = max(t - gap_open, E)), the diagonal step adds a constant 2 ge to the score,
+ *       and the boundary values of the first band width are constants.  `base` is raised by L16_DELTA whenever the
+ *       representation of an anti-diagonal maximum exceeds L16_REBASE, so sequence length does not limit the domain;
+ *       values are recovered (+ base - ge * d) where maxima of different anti-diagonals meet (z-drop, running
+ *       maximum).  Three disjoint zones: in-band values live in [L16_LO, ~L16_REBASE + 50 per anti-diagonal of a step];
+ *       the reference's -infinity and what is derived from it in [L16_GLO, L16_LO); cells outside the band below L16_GLO.
  *   (2) no per-cell band test.  Every cell of an active block is computed.  In a boundary block the band is cut by
- *       subtracting L16_CUT instead of the gap-extension score on one cell diagonal: E leaving the band to the right
- *       (cells with jl - il == tu) and F leaving it downwards (cells with il - jl == tl); state entering an
+ *       replacing E / F with L16_OUT on one cell diagonal: E leaving the band to the right (cells with jl - il == tu)
+ *       and F leaving it downwards (cells with il - jl == tl); state entering an
  *       out-of-band cell from a neighbouring block is replaced by L16_OUT.  Out-of-band cells therefore only ever
  *       hold values below L16_GLO, which lose every max against an in-band value, so in-band cells are unchanged;
  *       an anti-diagonal whose maximum is below L16_GLO has no in-band cell and is reported empty, as the
@@ -244,10 +248,9 @@ int agatha_model_lanes(const char *qs, int Q, const char *rs, int R, const lm_pa
  * ---------------------------------------------------------------------------------------------------
  */
 #define L16_LO     (-13000)    /* in-band values are >= L16_LO (enforced by the bail-out rule)                     */
-#define L16_NEG    (-13800)    /* the reference's -infinity; values derived from it stay in [L16_GLO, L16_LO)     */
-#define L16_GLO    (-14400)
-#define L16_OUT    (-30000)    /* state entering an out-of-band cell                                              */
-#define L16_CUT    17408       /* subtracted where E / F leave the band: lands below L16_GLO for any in-band value */
+#define L16_NEG    (-17500)    /* the reference's -infinity; values derived from it stay in [L16_GLO, L16_LO)     */
+#define L16_GLO    (-22000)
+#define L16_OUT    (-28000)    /* state entering an out-of-band cell, and E / F where they leave the band         */
 #define L16_REBASE 2048
 #define L16_DELTA  2048
 
@@ -274,10 +277,11 @@ static void init_col16(lane_t *ln, int s, int r, int R, int prl, int w, int gapo
 {
     for (int m = 0; m < 8; m++) {
         int c = 8 * r + m;
-        if (c < R && c <= w) { ln->h[s][m] = rep16(-(gapoe + ge * c) - base); ln->f[s][m] = rep16(-(gapoe + ge * c) - gapoe - base); }
+        /* H(-1, c) = -(gapoe + ge c) in the frame of anti-diagonal c - 1, F(0, c) = that - gapoe in frame c: constants */
+        if (c < R && c <= w) { ln->h[s][m] = rep16(-(gapoe + ge) - base); ln->f[s][m] = rep16(-2 * gapoe - base); }
         else { ln->h[s][m] = L16_NEG; ln->f[s][m] = L16_NEG; }
     }
-    ln->corner[s] = (r == 0) ? rep16(0 - base) : ((8 * r - 1) <= w ? rep16(-(gapoe + ge * (8 * r - 1)) - base) : L16_NEG);
+    ln->corner[s] = (r == 0) ? rep16(-2 * ge - base) : ((8 * r - 1) <= w ? rep16(-(gapoe + ge) - base) : L16_NEG);
     ln->rword[s] = (r < prl) ? pt[r] : 0xEEEEEEEEu;
     ln->rcur[s] = r;
 }
@@ -332,7 +336,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 for (int il = 0; il < 8; il++) {
                     int row = 8 * q + il;
                     if (left_ok) { xh[il] = ln->xh[s][il]; xe[il] = ln->xe[s][il]; }
-                    else if (row <= w) { xh[il] = rep16(-(gapoe + ge * row) - base); xe[il] = rep16(-(gapoe + ge * row) - gapoe - base); }
+                    else if (row <= w) { xh[il] = rep16(-(gapoe + ge) - base); xe[il] = rep16(-2 * gapoe - base); }
                     else { xh[il] = L16_NEG; xe[il] = L16_NEG; }
                 }
                 memcpy(xe_in, xe, sizeof(xe_in));
@@ -361,15 +365,15 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                         int sc = (qb == rb) ? a : -b;
                         if (qb == N_VALUE || rb == N_VALUE) sc = -1;
                         const int32_t d = jl == 0 ? (il == 0 ? cornerv : xh[il - 1]) : h[jl - 1];
-                        t[jl] = sc + d; TRACK(t[jl]);
+                        t[jl] = sc + 2 * ge + d; TRACK(t[jl]);           /* two anti-diagonals further: + 2 ge */
                     }
                     int32_t e = xe[il];
                     for (int jl = 0; jl < 8; jl++) {
                         const int out = !((jl - il) <= tu && (il - jl) <= tl);
                         const int32_t hn = imax(imax(t[jl], f[jl]), e);
                         const int32_t u = t[jl] - gapo; TRACK(u);
-                        f[jl] = imax(u, f[jl]) - ((il - jl) == tl ? L16_CUT : ge); TRACK(f[jl]);
-                        e = imax(u, e) - ((jl - il) == tu ? L16_CUT : ge); TRACK(e);
+                        f[jl] = (il - jl) == tl ? L16_OUT : imax(u, f[jl]); TRACK(f[jl]);
+                        e = (jl - il) == tu ? L16_OUT : imax(u, e); TRACK(e);
                         h[jl] = hn;
                         if (out) { if (hn > gmax) gmax = hn; }
                         else if (il < nrows) { if (hn < rmin) rmin = hn; }
@@ -382,7 +386,10 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                     oh[il] = h[7]; oe[il] = e;
                 }
                 for (int il = 0; il < 8; il++)
-                    if (il - 7 > tl) { oh[il] = oh[imax(0, tl + 7)]; oe[il] = xe_in[il]; }
+                    if (il - 7 > tl) {       /* the same VALUE is handed on for a row il - (tl + 7) anti-diagonals further down */
+                        const int32_t sv = oh[imax(0, tl + 7)];
+                        oh[il] = sv + ge * (il - imax(0, tl + 7)); oe[il] = xe_in[il];
+                    }
                 ln->corner[s] = xh[7];
                 memcpy(ln->xh[s + 1], oh, sizeof(oh)); memcpy(ln->xe[s + 1], oe, sizeof(oe));
                 ln->xr[s + 1] = r;
@@ -406,7 +413,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
             int H, c;
             if (v == INT_MIN || (v >> K) < L16_GLO) { H = -32768; c = 0; }      /* empty, or only out-of-band cells */
             else {
-                H = (v >> K) + base; c = (v & KMASK) + cb;
+                H = (v >> K) + base - ge * d; c = (v & KMASK) + cb;
                 if ((v >> K) < L16_LO + spread + L16_DELTA || H < NEG_INF2 + spread) { bail = 1; break; }
             }
             if (H > best) { best = H; best_t = c; best_q = d - c; }
