@@ -136,7 +136,9 @@ __device__ __forceinline__ uint32_t class_word(uint32_t qword) { return (qword >
 // signed bytes: column j in byte 3 - j/2 of the even (.x) or odd (.y) word of the profile row (wl: low half, wh: high).
 // Order: all low halves from column 7 down to 0, then all high halves: every add reads its left neighbour before that
 // neighbour is overwritten, and a half-register write is never read by the next instruction.
-__device__ __forceinline__ void row_add_scores(uint32_t (&h)[8], uint32_t d0, uint2 wl, uint2 wh)
+// Column 7's sum goes to t7 instead of h[7]: H(row, 7) is only ever read by the block to the right (row hand-off), never
+// as the state of column 7 (the diagonal of column 8 belongs to the next block), so it is produced where it is handed on.
+__device__ __forceinline__ void row_add_scores(uint32_t (&h)[8], uint32_t& t7, uint32_t d0, uint2 wl, uint2 wh)
 {
     asm("v_add_u16_sdwa %7, %6, sext(%10) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_0\n\t"
         "v_add_u16_sdwa %6, %5, sext(%9) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_0\n\t"
@@ -154,7 +156,7 @@ __device__ __forceinline__ void row_add_scores(uint32_t (&h)[8], uint32_t d0, ui
         "v_add_u16_sdwa %2, %1, sext(%11) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_2\n\t"
         "v_add_u16_sdwa %1, %0, sext(%12) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3\n\t"
         "v_add_u16_sdwa %0, %8, sext(%11) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3"
-        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7])
+        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(t7)
         : "v"(d0), "v"(wl.x), "v"(wl.y), "v"(wh.x), "v"(wh.y));
 }
 
@@ -245,7 +247,8 @@ __device__ __forceinline__ void block_row16(uint32_t (&h)[8], uint32_t (&f)[8], 
 {
     // key multiplier of this row: 2^K where the row exists (IL < rows), 0 where it does not
     const uint32_t kmul = pk_min_c(pk_sub_sat_c(o.NRK, dup2((uint32_t)(IL << K))), dup2(1u << K));
-    row_add_scores(h, d0, wl, wh);
+    uint32_t& t7 = oh[IL];
+    row_add_scores(h, t7, d0, wl, wh);
     if (IL < 7) {
         wl = profile_row(o.pl, o.qc_lo, 24 - 4 * IL);
         wh = profile_row(o.ph, o.qc_hi, 24 - 4 * IL);
@@ -254,10 +257,10 @@ __device__ __forceinline__ void block_row16(uint32_t (&h)[8], uint32_t (&f)[8], 
     // E is cut on cell diagonal jl - il == T0 (upper edge blocks) or T0 + 8 (the block next to the corner of the band),
     // F on il - jl == T0 or T0 + 8 (lower edge blocks)
     row_cells4<cut_mask4<T0>(IL, 0, false), cut_mask4<T0>(IL, 0, true)>(h[0], h[1], h[2], h[3], f[0], f[1], f[2], f[3], ev, o.gapo2, o.cl, o.cl2, o.cu, o.cu2);
-    row_cells4<cut_mask4<T0>(IL, 4, false), cut_mask4<T0>(IL, 4, true)>(h[4], h[5], h[6], h[7], f[4], f[5], f[6], f[7], ev, o.gapo2, o.cl, o.cl2, o.cu, o.cu2);
+    row_cells4<cut_mask4<T0>(IL, 4, false), cut_mask4<T0>(IL, 4, true)>(h[4], h[5], h[6], t7, f[4], f[5], f[6], f[7], ev, o.gapo2, o.cl, o.cl2, o.cu, o.cu2);
     row_keys4(A[IL], A[IL + 1], A[IL + 2], A[IL + 3], h[0], h[1], h[2], h[3], kmul, o.crel_lo - IL, o.crel_hi - IL);
-    row_keys4(A[IL + 4], A[IL + 5], A[IL + 6], A[IL + 7], h[4], h[5], h[6], h[7], kmul, o.crel_lo - IL, o.crel_hi - IL);
-    oh[IL] = h[7]; e[IL] = ev;
+    row_keys4(A[IL + 4], A[IL + 5], A[IL + 6], A[IL + 7], h[4], h[5], h[6], t7, kmul, o.crel_lo - IL, o.crel_hi - IL);
+    e[IL] = ev;
 }
 
 template <int K, int T0>
