@@ -755,12 +755,12 @@ hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool fo
     if (have16) {
         KernelChoice k;
         k.kind = 1; k.G = G16; k.S = 2 * P16;
-        k.t_lat = 2.0f * P16 + 2.0f; k.t_load = 5.0f * P16;
+        k.t_lat = 1.75f * P16 + 1.75f; k.t_load = 4.45f * P16;
         k.capacity = L.num_cus * 8 * (64 / G16);
         L.cand[L.ncand++] = k;
         if (GL16 && !force16) {
             k.G = GL16; k.S = 2 * PL16;
-            k.t_lat = 2.0f * PL16 + 2.0f; k.t_load = 5.0f * PL16;
+            k.t_lat = 1.75f * PL16 + 1.75f; k.t_load = 4.45f * PL16;
             k.capacity = L.num_cus * 8 * (64 / GL16);
             L.cand[L.ncand++] = k;
         }

@@ -25,8 +25,8 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # instruction; tools/microbench/valu_rate.hip, profiles/r01_v1/valu_issue_rate_microbench.txt) -> 256 CU x 4 SIMD x 16 x 2.4 GHz
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # algorithmic VALU lane-ops of one DP cell incl. the anti-diagonal maximum: 11 int32 ops per cell in the
-# int32 kernel; 12 packed ops per TWO cells in the packed-int16 kernel (2 score adds, 4 max, 3 sub, 2 key mads, 1 max3)
-OPS_PER_CELL = {"int32": 11.0, "int16": 6.0}
+# int32 kernel; 10 packed ops per TWO cells in the packed-int16 kernel (2 score adds, 4 max, 1 sub, 2 key mads, 1 max3)
+OPS_PER_CELL = {"int32": 11.0, "int16": 5.0}
 
 
 def algorithmic_bytes(qlen, tlen):
