@@ -151,6 +151,23 @@ def test_rebasing_long_pairs(eng):
     assert int(np.max(exp[0])) > 40000
 
 
+@pytest.mark.parametrize("p", [dict(m=16, x=32, q=64, r=16, s=3, z=400, w=103), dict(m=16, x=1, q=0, r=16, s=2, z=-1, w=250),
+                               dict(m=1, x=4, q=6, r=0, s=3, z=400, w=751), dict(m=2, x=4, q=4, r=2, s=3, z=-1, w=751),
+                               dict(m=1, x=32, q=64, r=1, s=3, z=-1, w=97)],
+                         ids=lambda p: "m%dx%dq%dr%ds%dz%dw%d" % (p["m"], p["x"], p["q"], p["r"], p["s"], p["z"], p["w"]))
+def test_drifting_frame_extremes(eng, p):
+    """The int16 kernel sees every value from its own anti-diagonal (+ ge per anti-diagonal): with the steepest scores
+    the representation is rebased every ~10 steps of a 2 x 30 kb pair, with r = 0 the frame does not move at all, and
+    with z-drop off on noisy and broken pairs the values fall while the frame rises."""
+    rng = np.random.default_rng(77)
+    qs, ts = WL.make_pairs(11, 10, lambda r: int(r.integers(20000, 30001)), 0.01, 0.01, 0.01)
+    q2, t2 = WL.make_pairs(12, 10, lambda r: int(r.integers(3000, 9000)), 0.12, 0.08, 0.08)
+    q3, t3 = WL.cfg_c4(n=40, seed=13, lo=100, hi=12000)
+    got, exp, kinds = _run_with_kinds(eng, qs + q2 + q3, ts + t2 + t3, p)
+    assert _same(got, exp)
+    assert eng.last_int16_config() == _expected_int16_config(p)
+
+
 def test_pairs_the_int16_kernel_hands_back(eng):
     """z-drop switched off on unrelated sequences: the scores sink until they come within `spread` of the reference's
     -infinity, where the int16 kernel abandons the pair (bail-out) and the int32 kernel redoes it (in the kernel's
