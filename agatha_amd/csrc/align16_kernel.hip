@@ -44,8 +44,14 @@ constexpr int LO = -13000 + BIAS;        // in-band values are >= LO (bail-out r
 constexpr int NEG = -17500 + BIAS;       // the reference's -infinity
 constexpr int GLO = -22000 + BIAS;       // below: out-of-band cells / nothing
 constexpr int OUT = -28000 + BIAS;       // state entering an out-of-band cell; E / F where they leave the band
-constexpr int REBASE = 2048 + BIAS;      // rebase when an anti-diagonal maximum exceeds this
+constexpr int REBASE = 2048 + BIAS;      // (+ lift) rebase when an anti-diagonal maximum exceeds this
 constexpr int DELTA = 2048;
+// In-band cells lie up to `spread` below the maximum of their anti-diagonal.  Up to FREE_SPREAD that fits between LO and a
+// representation that starts at BIAS; for steeper scores the in-band zone is lifted (a pair starts with base = -lift) into
+// the range above REBASE that is otherwise unused.  Beyond MAX_SPREAD a pair would be abandoned on its first
+// anti-diagonal (its in-band cells would reach down to the reference's -infinity): the launcher does not offer the kernel.
+constexpr int FREE_SPREAD = 7000;
+constexpr int MAX_SPREAD = 16000;
 }  // namespace r16
 
 __device__ __forceinline__ uint32_t pk2(uint32_t lo, uint32_t hi) { return (lo & 0xffffu) | (hi << 16); }
@@ -323,6 +329,8 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
     }
     // (+ 7 ge: the maxima of a step's eight anti-diagonals are compared after moving them to the frame of the first)
     const int bail_rep = r16::LO + spread + r16::DELTA + 7 * ge;
+    const int lift = spread > r16::FREE_SPREAD ? spread - r16::FREE_SPREAD : 0;
+    const int rebase_at = r16::REBASE + lift;
     const int frame_mul = 1 - (ge << K);           // A[x] + x * frame_mul: column + x, H field - ge * x
     const uint32_t GAPO2 = dup2((uint32_t)gapo);
     const uint32_t NEG2 = dup2(r16::NEG), OUT2 = dup2(r16::OUT), ONE2 = 0x00010001u, K2 = dup2(K), F15 = 0x000F000Fu;
@@ -372,7 +380,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
                         pq = La->qoffs[pair] >> 3;
                         pt = La->toffs[pair] >> 3;
                         const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
-                        best = 0; best_t = 0; best_q = 0; base = 0;
+                        best = 0; best_t = 0; best_q = 0; base = -lift;
                         // The pair starts with a dry step i = -1: no block is active in it, and the code that puts the
                         // initial column state back into slots that have not started yet (below, after each block pair)
                         // thereby initialises every slot.  Assigning that state here instead would make the register
@@ -740,7 +748,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
 
         // ---- rebase: keep the representation of the running maximum small ----
         {
-            const bool reb = alive && !finished && !bail && (hi8 >> K) > r16::REBASE;
+            const bool reb = alive && !finished && !bail && (hi8 >> K) > rebase_at;
             if (__builtin_expect(__any(reb), 0)) {
                 const uint32_t D2 = reb ? dup2(r16::DELTA) : 0u;
                 const uint32_t CAP2 = dup2(r16::LO - 1);
@@ -827,7 +835,7 @@ bool agatha16_scores_ok(const AlignParams& p)
     if (p.gap_open < 0 || p.gap_open > 64 || p.gap_extend < 0 || p.gap_extend > 16) return false;
     int per = 2 * p.gap_extend; if (p.mismatch > per) per = p.mismatch; if (per < 1) per = 1;
     const int spread = p.gap_open + p.gap_extend + per * (p.band_width + 16) + 64;
-    return spread <= 7000;
+    return spread <= r16::MAX_SPREAD;
 }
 
 // the smallest packed-int16 configuration that holds the window, unless it would leave most of its slots idle

@@ -251,8 +251,14 @@ int agatha_model_lanes(const char *qs, int Q, const char *rs, int R, const lm_pa
 #define L16_NEG    (-17500)    /* the reference's -infinity; values derived from it stay in [L16_GLO, L16_LO)     */
 #define L16_GLO    (-22000)
 #define L16_OUT    (-28000)    /* state entering an out-of-band cell, and E / F where they leave the band         */
-#define L16_REBASE 2048
+#define L16_REBASE 2048        /* + lift: rebase when the representation of an anti-diagonal maximum exceeds this    */
 #define L16_DELTA  2048
+/* In-band cells can lie up to `spread` below the maximum of their anti-diagonal.  Up to 7000 that fits between L16_LO and
+ * a representation that starts at 0; for steeper scores / wider bands the whole in-band zone is lifted (the pair starts
+ * with base = -lift), which the unused range above L16_REBASE has room for.  Beyond L16_MAX_SPREAD a pair would be
+ * abandoned at once: its in-band cells reach down to the reference's -infinity from the first anti-diagonal on. */
+#define L16_FREE_SPREAD 7000
+#define L16_MAX_SPREAD  16000
 
 int agatha_lanes16_spread(const lm_params_t *pr)
 {
@@ -267,7 +273,7 @@ int agatha_lanes16_eligible(const lm_params_t *pr)
     if (pr->band_width < 16) return 0;
     if (pr->match < 0 || pr->match > 16 || pr->mismatch < 0 || pr->mismatch > 32) return 0;
     if (pr->gap_open < 0 || pr->gap_open > 64 || pr->gap_extend < 0 || pr->gap_extend > 16) return 0;
-    if (agatha_lanes16_spread(pr) > 7000) return 0;
+    if (agatha_lanes16_spread(pr) > L16_MAX_SPREAD) return 0;
     return 1;
 }
 
@@ -305,7 +311,8 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
     pack_words(qs, Q, pq, pql); pack_words(rs, R, pt, prl);
 
     lane_t *L = (lane_t *)calloc((size_t)G, sizeof(lane_t));
-    int base = 0;
+    const int lift = spread > L16_FREE_SPREAD ? spread - L16_FREE_SPREAD : 0;
+    int base = -lift;
     for (int k = 0; k < G; k++) {
         for (int s = 0; s < S; s++) init_col16(&L[k], s, k * S + s, R, prl, w, gapoe, ge, base, pt);
         for (int s = 0; s <= S; s++) L[k].xr[s] = -2;
@@ -430,7 +437,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
         }
         cb_prev = cb;
         /* rebase: keep the representation of the running maximum small */
-        if (hi_rep > L16_REBASE) {
+        if (hi_rep > L16_REBASE + lift) {
             base += L16_DELTA;
             for (int k = 0; k < G; k++) {
                 lane_t *ln = &L[k];

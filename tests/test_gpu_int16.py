@@ -76,7 +76,7 @@ def _expected_int16_config(p):
     """(lanes per pair, slots per lane) the launcher must choose, or None (agatha_amd/csrc/align16_kernel.hip: pick16)."""
     W = (p["w"] + 7) // 8
     per = max(2 * p["r"], p["x"], 1)
-    if p["w"] < 16 or p["q"] + p["r"] + per * (p["w"] + 16) + 64 > 7000:
+    if p["w"] < 16 or p["q"] + p["r"] + per * (p["w"] + 16) + 64 > 16000:
         return None
     for G, S in ((16, 2), (16, 4), (16, 6), (32, 4), (32, 6)):
         if G * S >= W + 1:
@@ -153,12 +153,14 @@ def test_rebasing_long_pairs(eng):
 
 @pytest.mark.parametrize("p", [dict(m=16, x=32, q=64, r=16, s=3, z=400, w=103), dict(m=16, x=1, q=0, r=16, s=2, z=-1, w=250),
                                dict(m=1, x=4, q=6, r=0, s=3, z=400, w=751), dict(m=2, x=4, q=4, r=2, s=3, z=-1, w=751),
-                               dict(m=1, x=32, q=64, r=1, s=3, z=-1, w=97)],
+                               dict(m=1, x=32, q=64, r=1, s=3, z=-1, w=97), dict(m=1, x=19, q=39, r=3, s=3, z=400, w=751),
+                               dict(m=2, x=12, q=24, r=2, s=3, z=1000, w=1000), dict(m=2, x=32, q=64, r=2, s=2, z=400, w=400)],
                          ids=lambda p: "m%dx%dq%dr%ds%dz%dw%d" % (p["m"], p["x"], p["q"], p["r"], p["s"], p["z"], p["w"]))
 def test_drifting_frame_extremes(eng, p):
     """The int16 kernel sees every value from its own anti-diagonal (+ ge per anti-diagonal): with the steepest scores
     the representation is rebased every ~10 steps of a 2 x 30 kb pair, with r = 0 the frame does not move at all, and
-    with z-drop off on noisy and broken pairs the values fall while the frame rises."""
+    with z-drop off on noisy and broken pairs the values fall while the frame rises; with steep mismatch penalties
+    (in-band cells up to 16 000 below their anti-diagonal's maximum) the in-band zone starts lifted."""
     rng = np.random.default_rng(77)
     qs, ts = WL.make_pairs(11, 10, lambda r: int(r.integers(20000, 30001)), 0.01, 0.01, 0.01)
     q2, t2 = WL.make_pairs(12, 10, lambda r: int(r.integers(3000, 9000)), 0.12, 0.08, 0.08)
@@ -166,6 +168,17 @@ def test_drifting_frame_extremes(eng, p):
     got, exp, kinds = _run_with_kinds(eng, qs + q2 + q3, ts + t2 + t3, p)
     assert _same(got, exp)
     assert eng.last_int16_config() == _expected_int16_config(p)
+
+
+def test_steep_scores_stay_on_the_int16_kernel(eng):
+    """minimap2's asm5 scoring at band 751 (in-band cells up to 14 679 below a maximum): good pairs are finished by the
+    int16 kernel itself, with the in-band zone lifted; nothing is handed back."""
+    p = dict(m=1, x=19, q=39, r=3, s=3, z=400, w=751)
+    qs, ts = WL.make_pairs(21, 48, lambda r: int(r.integers(6000, 14001)), 0.004, 0.002, 0.002)
+    got, exp, kinds = _run_with_kinds(eng, qs, ts, p)
+    assert _same(got, exp)
+    assert eng.last_int16_config() == (16, 6)
+    assert tuple(int(v) for v in kinds) == (48, 0, 0)
 
 
 def test_pairs_the_int16_kernel_hands_back(eng):

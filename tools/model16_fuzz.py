@@ -9,7 +9,7 @@ from tests.test_oracle import _mixed_pairs
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-SC = [(2, 4, 4, 2), (1, 4, 6, 2), (2, 3, 5, 1), (3, 5, 0, 1), (1, 1, 1, 1), (16, 32, 64, 16), (16, 0, 0, 16), (0, 32, 64, 0), (5, 4, 10, 16), (16, 32, 0, 0)]
+SC = [(2, 4, 4, 2), (1, 4, 6, 2), (2, 3, 5, 1), (3, 5, 0, 1), (1, 1, 1, 1), (16, 32, 64, 16), (16, 0, 0, 16), (0, 32, 64, 0), (5, 4, 10, 16), (16, 32, 0, 0), (1, 19, 39, 3), (2, 32, 64, 2), (1, 32, 10, 1), (2, 24, 4, 2)]
 gmin, gmax, garb, rmin, nb, npairs, bad = 0, 0, -10**9, 10**9, 0, 0, 0
 for t in range(trials):
     w = int(rng.choice([16, 17, 18, 19, 20, 21, 22, 23, 24, 33, 47, 64, 100, 200, 333, 751]))
