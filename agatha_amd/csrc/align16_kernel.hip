@@ -73,6 +73,7 @@ __device__ __forceinline__ uint32_t pk_shl(uint32_t a, uint32_t sh2) { uint32_t 
 __device__ __forceinline__ int mad_lo(uint32_t h, uint32_t m, int c) { int d; asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(h), "v"(m), "v"(c)); return d; }
 __device__ __forceinline__ int mad_hi(uint32_t h, uint32_t m, int c) { int d; asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(h), "v"(m), "v"(c)); return d; }
 __device__ __forceinline__ int max3i(int a, int b, int c) { int d; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ int min3i(int a, int b, int c) { int d; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
 // representation of an in-band boundary value (value - base), or -infinity when it is out of the in-band zone
 __device__ __forceinline__ uint32_t rep16(int v_minus_base)
@@ -294,6 +295,27 @@ __device__ __forceinline__ uint32_t lt_mask(uint32_t a, uint32_t b, uint32_t f15
 // a == b
 __device__ __forceinline__ uint32_t eq_mask(uint32_t a, uint32_t b, uint32_t one2) { return pk_sub_c(pk_min_c(a ^ b, one2), one2); }
 
+// maxima over the G lanes of a group, result in every lane: two signed values and one unsigned at once (DPP row rotations
+// inside a 16-lane row, ds_bpermute across rows)
+template <int G>
+__device__ __forceinline__ void group_max3(int& a, int& b, uint32_t& c, int lane)
+{
+#define AGATHA16_DPP_STAGE(CTRL) \
+    { const int ta = __builtin_amdgcn_update_dpp(INT_MIN, a, CTRL, 0xf, 0xf, true), tb = __builtin_amdgcn_update_dpp(INT_MIN, b, CTRL, 0xf, 0xf, true); \
+      const uint32_t tc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, CTRL, 0xf, 0xf, true); \
+      a = imax(a, ta); b = imax(b, tb); c = c > tc ? c : tc; }
+    AGATHA16_DPP_STAGE(0x121) AGATHA16_DPP_STAGE(0x122) AGATHA16_DPP_STAGE(0x124) AGATHA16_DPP_STAGE(0x128)
+#undef AGATHA16_DPP_STAGE
+    if (G >= 32) {
+        const int ta = lane_read(a, lane ^ 16), tb = lane_read(b, lane ^ 16); const uint32_t tc = (uint32_t)lane_read((int)c, lane ^ 16);
+        a = imax(a, ta); b = imax(b, tb); c = c > tc ? c : tc;
+    }
+    if (G >= 64) {
+        const int ta = lane_read(a, lane ^ 32), tb = lane_read(b, lane ^ 32); const uint32_t tc = (uint32_t)lane_read((int)c, lane ^ 32);
+        a = imax(a, ta); b = imax(b, tb); c = c > tc ? c : tc;
+    }
+}
+
 template <int G, int P, int T0>
 __global__ void __launch_bounds__(256, 2)
 align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
@@ -331,7 +353,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
     const int bail_rep = r16::LO + spread + r16::DELTA + 7 * ge;
     const int lift = spread > r16::FREE_SPREAD ? spread - r16::FREE_SPREAD : 0;
     const int rebase_at = r16::REBASE + lift;
-    const int frame_mul = 1 - (ge << K);           // A[x] + x * frame_mul: column + x, H field - ge * x
+    const int frame_step = ge << K;                // + (7 - x) * frame_step: H field of anti-diagonal x seen from the step's last one
     const uint32_t GAPO2 = dup2((uint32_t)gapo);
     const uint32_t NEG2 = dup2(r16::NEG), OUT2 = dup2(r16::OUT), ONE2 = 0x00010001u, K2 = dup2(K), F15 = 0x000F000Fu;
     const uint32_t W2 = dup2((uint32_t)W), NOTAG = 0xFFFEFFFEu;
@@ -689,13 +711,29 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
         // ------------------------------------------------------------------ anti-diagonals 8i..8i+7 are complete
         bool stopped = false;
         int vred[8];
+        // H fields are moved to the frame of the step's LAST anti-diagonal (+ (7 - x) ge): they only grow, so that the key
+        // of an accumulator without a cell stays a small non-negative number (see row_keys4 for the + x)
 #pragma unroll
-        for (int x = 0; x < 8; x++) vred[x] = A[x] + x * frame_mul;        // see row_keys4; H fields now in the frame of 8i
-        const int base_i = base - 8 * ge * i;                               // value = rep - BIAS + base_i there
-        group_max8<G>(vred, lane);
-        int lo8 = vred[0], hi8 = vred[0];
+        for (int x = 0; x < 8; x++) vred[x] = A[x] + (x + (7 - x) * frame_step);
+        const int base_i = base - ge * (8 * i + 7);                         // value = rep - BIAS + base_i there
+        // Per lane first, then ONE reduction of three numbers over the group instead of eight: the largest key of the step
+        // (rebase, calm test), a LOWER BOUND of the smallest anti-diagonal maximum (the largest, over the lanes, of a
+        // lane's smallest accumulator: the lane that holds the best cells has cells on all eight anti-diagonals), and the
+        // best (H : earliest anti-diagonal : column) -- each key's order is kept by its own transformation, so the maximum
+        // over lanes and anti-diagonals of the transformed keys is the transformed maximum.
+        static_assert(K + 3 + 16 <= 32, "key of the fast path");
+        int hi8 = max3i(vred[0], vred[1], vred[2]), lo8 = min3i(vred[0], vred[1], vred[2]);
+        hi8 = max3i(hi8, vred[3], vred[4]); lo8 = min3i(lo8, vred[3], vred[4]);
+        hi8 = max3i(hi8, vred[5], vred[6]); lo8 = min3i(lo8, vred[5], vred[6]);
+        hi8 = imax(hi8, vred[7]); lo8 = imin(lo8, vred[7]);
+        uint32_t mk = 0u;
 #pragma unroll
-        for (int x = 1; x < 8; x++) { lo8 = imin(lo8, vred[x]); hi8 = imax(hi8, vred[x]); }
+        for (int x = 0; x < 8; x++) {
+            const uint32_t v = (uint32_t)vred[x];
+            const uint32_t k3 = ((v & ~(uint32_t)KMASK) << 3) | ((uint32_t)(7 - x) << K) | (v & (uint32_t)KMASK);
+            mk = k3 > mk ? k3 : mk;
+        }
+        group_max3<G>(hi8, lo8, mk, lane);
         // Fast path (wave-uniform): every anti-diagonal of this step has an in-band maximum well inside its zone, inside
         // the pair, and within z of the running maximum, so neither z-drop nor the bail-out can fire.
         bool calm = !final_step && (8 * i + 7 < lim) && !bail;
@@ -705,20 +743,13 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
         }
         if (__builtin_expect(__all(calm || !alive), 1)) {
             // only the running maximum moves: the anti-diagonal with the largest H wins, the earliest one among equals
-            // (the reference walks them in order and updates on H > max only); one max over H : 7 - x : column
-            static_assert(K + 3 + 16 <= 32, "key of the fast path");
-            uint32_t mk = 0u;
-#pragma unroll
-            for (int x = 0; x < 8; x++) {
-                const uint32_t v = (uint32_t)vred[x];
-                const uint32_t k3 = ((v & ~(uint32_t)KMASK) << 3) | ((uint32_t)(7 - x) << K) | (v & (uint32_t)KMASK);
-                mk = k3 > mk ? k3 : mk;
-            }
+            // (the reference walks them in order and updates on H > max only)
             const int Hm = (int)(mk >> (K + 3)) - r16::BIAS + base_i;
             if (alive && Hm > best) {
                 best = Hm; best_t = (int)(mk & (uint32_t)KMASK) + cb; best_q = 8 * i + 7 - (int)((mk >> K) & 7u) - best_t;
             }
         } else {
+            group_max8<G>(vred, lane);
 #pragma unroll
             for (int x = 0; x < 8; x++) {
                 const int v = vred[x];
