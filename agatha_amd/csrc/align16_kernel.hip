@@ -695,7 +695,9 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
 #pragma unroll
             for (int il = 0; il < 8; il++) {
                 // a 16-lane group is one DPP row: row_ror:1 hands every lane the value of its left neighbour (wrapping)
+                // (a 64-lane group is the wave: wave_ror:1 does the same there)
                 if (G == 16) th[il] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)XH[P - 1][il], 0x121, 0xf, 0xf, true);
+                else if (G == 64) th[il] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)XH[P - 1][il], 0x13C, 0xf, 0xf, true);
                 else th[il] = (uint32_t)lane_read((int)XH[P - 1][il], left_lane);
             }
 #pragma unroll
