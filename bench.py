@@ -49,7 +49,7 @@ def effective_cpus():
     return max(1, n)
 
 
-def cpu_baseline(qb, tb, qo, to, ql, tl, scoring, w, budget_s=12.0):
+def cpu_baseline(qb, tb, qo, to, ql, tl, scoring, w, budget_s=12.0, gpu_res=None):
     """CPU baseline on the GPU box's own host cores, bounded sample of the same batch, OpenMP over pairs:
     the anti-diagonal AVX2 int16 kernel oracle/ksw_style_avx2.c (own code in the manner of minimap2's ksw_extz2_sse,
     which is not available here) and, beside it, the scalar C oracle.  Both are "port" (not the reference's own code:
@@ -80,7 +80,12 @@ def cpu_baseline(qb, tb, qo, to, ql, tl, scoring, w, budget_s=12.0):
     r_scal, dts = timed(scal, ks)
     same = int(sum(int((r_simd[0][i] == r_scal[0][i]) and (r_simd[1][i] == r_scal[1][i]) and (r_simd[2][i] == r_scal[2][i]))
                    for i in range(ks)))
-    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+    checked = None
+    if gpu_res is not None:                 # the CPU results double as a check of the timed GPU step (checker only)
+        ok_simd = int(sum(int(all(int(gpu_res[j][i]) == int(r_simd[j][i]) for j in range(3))) for i in range(k)))
+        ok_scal = int(sum(int(all(int(gpu_res[j][i]) == int(r_scal[j][i]) for j in range(3))) for i in range(ks)))
+        checked = f"GPU results of the last timed step: {ok_simd}/{k} pairs identical to the AVX2 port, {ok_scal}/{ks} to the scalar oracle"
+    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port", "gpu_results_checked": checked,
             "sample": f"first {k} pairs of the same batch x{reps} in {dt:.1f} s: anti-diagonal AVX2 int16 kernel "
                       f"(oracle/ksw_style_avx2.c, ksw_extz2-style, exact band), OpenMP schedule(dynamic) over pairs; "
                       f"{r_simd[3]} pairs fell back to scalar (outside int16)",
@@ -235,7 +240,9 @@ def main():
                                       "rate of the chip; the int16 kernel does two cells per packed lane-op"},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(qb, tb, qo, to, ql, tl, dict(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND), W_BAND)
+            gpu_res = tuple(np.array(b.res_host[j][:b.n]) for j in range(3))      # downloaded by the last step
+            out["cpu_baseline"] = cpu_baseline(qb, tb, qo, to, ql, tl, dict(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND), W_BAND,
+                                               gpu_res=gpu_res)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
