@@ -386,13 +386,38 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
 #pragma unroll
     for (int x = 0; x < 15; x++) A[x] = 0;
 
+    // First round of a full grid (two workgroups per CU, all resident): the workgroups b and b + gridDim/2 share a CU, wave
+    // by wave a SIMD, so WHICH 16 queue positions a workgroup starts with decides which waves share a SIMD.  The
+    // workgroups that will take a second pair (the C chunks with the shortest first-round pairs; BASELINE: 10 000 pairs on
+    // 8192 lane groups) are the critical path, and they run alone -- 1.4x faster per step -- as soon as the wave they share
+    // the SIMD with has finished: they get the shortest single-round chunks as partners, and the remaining chunks are
+    // paired longest with shortest.  Later pairs come from the atomic queue, which then starts behind the first round.
+    constexpr int GPB = 4 * (64 / G);                  // lane groups per workgroup
+    const int nblk = (int)gridDim.x, cap = nblk * GPB;
+    int chain_chunks = (La->n - cap + GPB - 1) / GPB;
+    const bool deal = (nblk == 2 * La->num_cus) && La->n >= cap && 2 * chain_chunks <= nblk;
+    bool first_round = deal;
+    int first_idx = 0;
+    if (deal) {
+        const int Hh = nblk / 2, C = chain_chunks, bb = (int)blockIdx.x;
+        const int a = bb < Hh ? bb : bb - Hh;
+        int chunk;
+        if (bb < Hh) chunk = a < C ? nblk - C - 1 - a : a - C;
+        else chunk = a < C ? nblk - 1 - a : nblk - 2 * C - 1 - (a - C);
+        first_idx = chunk * GPB + (int)(threadIdx.x >> 6) * (64 / G) + lane / G;
+    }
+
     for (;;) {
         // ------------------------------------------------------------------ work queue
         const bool need = !alive && !exhausted;
         if (__builtin_expect(__any(need), 0)) {
             int idx = 0;
-            if (need && k == 0) idx = (int)atomicAdd(La->queue + 0, 1u);
-            idx = lane_read(idx, gbase);
+            if (first_round) idx = first_idx;
+            else {
+                if (need && k == 0) idx = (int)atomicAdd(La->queue + 0, 1u) + (deal ? cap : 0);
+                idx = lane_read(idx, gbase);
+            }
+            first_round = false;
             if (need) {
                 if (idx >= La->n) exhausted = true;
                 else {

@@ -230,6 +230,34 @@ def test_n_in_query_and_other_letters_are_routed(eng):
     assert _same(got, exp)
 
 
+@pytest.mark.parametrize("n", [8192, 8200, 9000, 12288, 12300])
+def test_first_round_dealt_to_the_workgroups(eng, n):
+    """With a full grid (8192 lane groups for a narrow band) and between 1 and 1.5 rounds of pairs the int16 kernel deals
+    the first round to the workgroups by formula (which waves share a SIMD) and takes the rest from the queue; pairs
+    the kernel must skip (N in the query, other letters) sit in the dealt range as well.  12 300 pairs: plain queue."""
+    rng = np.random.default_rng(n)
+    qs, ts = [], []
+    for k in range(n):
+        ref = WL.random_seq(rng, int(rng.integers(40, 260)))
+        rd = WL.mutate(rng, ref, 0.03, 0.03, 0.04)
+        if rd.size == 0:
+            rd = WL.random_seq(rng, 1)
+        ref, rd = ref.copy(), rd.copy()
+        if k % 97 == 5:
+            ref[rng.integers(0, ref.size)] = ord("N")          # N in the query (file 1): int32 profile kernel
+        if k % 89 == 7:
+            rd[rng.integers(0, rd.size)] = ord("R")            # other letter: compare kernel
+        qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    p = dict(BASE, w=24)
+    os.environ["AGATHA_AMD_FORCE_CHOICE"] = "0"                # the int16 throughput shape <16,1>: 16 groups per workgroup
+    try:
+        got, exp, kinds = _run_with_kinds(eng, qs, ts, p)
+    finally:
+        del os.environ["AGATHA_AMD_FORCE_CHOICE"]
+    assert _same(got, exp)
+    assert int(kinds[1]) > 0 and int(kinds[2]) > 0
+
+
 def test_ragged_lengths_around_block_edges(eng):
     """Every query length modulo 8 (rows that do not exist in the last row block) against every target length modulo 8
     (padded reference columns)."""
