@@ -395,7 +395,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
     constexpr int GPB = 4 * (64 / G);                  // lane groups per workgroup
     const int nblk = (int)gridDim.x, cap = nblk * GPB;
     int chain_chunks = (La->n - cap + GPB - 1) / GPB;
-    const bool deal = (nblk == 2 * La->num_cus) && La->n >= cap && 2 * chain_chunks <= nblk;
+    const bool deal = (nblk == 2 * La->num_cus) && La->n >= cap && 2 * chain_chunks <= nblk && !La->no_deal;
     bool first_round = deal;
     int first_idx = 0;
     if (deal) {

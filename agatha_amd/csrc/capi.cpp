@@ -143,6 +143,7 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.force_cmp = (sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     HIPCHK(agatha::launch_exotic(L, st));
     { const char* e = getenv("AGATHA_AMD_MAX_BLOCKS"); L.max_blocks_override = e ? atoi(e) : 0; }
+    { const char* e = getenv("AGATHA_AMD_NO_DEAL"); L.no_deal = (e && atoi(e)) ? 1 : 0; }
     // Candidates for the plain pairs: the packed-int16 kernel when the scores and the band allow it, the int32 kernel
     // in its throughput shape and in its latency shape; which one runs is decided on the device from the batch's length
     // histogram (record_kernel).  AGATHA_AMD_NO_INT16=1 removes the int16 kernel, AGATHA_AMD_FORCE_INT16=1 makes it the

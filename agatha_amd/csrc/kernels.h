@@ -34,6 +34,7 @@ struct AlignLaunch {
     AlignParams p;
     int num_cus;
     int max_blocks_override;       // > 0: cap of the persistent grid (tuning knob, AGATHA_AMD_MAX_BLOCKS)
+    int no_deal;                   // 1 = every pair from the queue, no dealt first round (AGATHA_AMD_NO_DEAL, A/B runs)
     const AlignLaunch* self_dev;   // device copy of this record (lives in the workspace)
 };
 
