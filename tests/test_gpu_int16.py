@@ -258,6 +258,14 @@ def test_first_round_dealt_to_the_workgroups(eng, n):
     assert int(kinds[1]) > 0 and int(kinds[2]) > 0
 
 
+def test_first_round_dealt_in_the_latency_shape(eng):
+    """2100 pairs at band 751: the device picks the 64-lane shape (2048 lane groups), whose first round is dealt as well."""
+    qs, ts = WL.make_pairs(77, 2100, lambda r: int(r.integers(1500, 3500)), 0.03, 0.03, 0.04)
+    got, exp, kinds = _run_with_kinds(eng, qs, ts, BASE)
+    assert _same(got, exp)
+    assert tuple(int(v) for v in kinds) == (2100, 0, 0)
+
+
 def test_ragged_lengths_around_block_edges(eng):
     """Every query length modulo 8 (rows that do not exist in the last row block) against every target length modulo 8
     (padded reference columns)."""
