@@ -392,18 +392,28 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
     // 8192 lane groups) are the critical path, and they run alone -- 1.4x faster per step -- as soon as the wave they share
     // the SIMD with has finished: they get the shortest single-round chunks as partners, and the remaining chunks are
     // paired longest with shortest.  Later pairs come from the atomic queue, which then starts behind the first round.
+    // (Up to two rounds; beyond that every pair comes from the queue.)
     constexpr int GPB = 4 * (64 / G);                  // lane groups per workgroup
     const int nblk = (int)gridDim.x, cap = nblk * GPB;
     int chain_chunks = (La->n - cap + GPB - 1) / GPB;
-    const bool deal = (nblk == 2 * La->num_cus) && La->n >= cap && 2 * chain_chunks <= nblk && !La->no_deal;
+    const bool deal = (nblk == 2 * La->num_cus) && La->n >= cap && chain_chunks <= nblk && !La->no_deal;
     bool first_round = deal;
     int first_idx = 0;
     if (deal) {
         const int Hh = nblk / 2, C = chain_chunks, bb = (int)blockIdx.x;
         const int a = bb < Hh ? bb : bb - Hh;
         int chunk;
-        if (bb < Hh) chunk = a < C ? nblk - C - 1 - a : a - C;
-        else chunk = a < C ? nblk - 1 - a : nblk - 2 * C - 1 - (a - C);
+        if (C <= Hh) {
+            if (bb < Hh) chunk = a < C ? nblk - C - 1 - a : a - C;
+            else chunk = a < C ? nblk - 1 - a : nblk - 2 * C - 1 - (a - C);
+        } else {
+            // 1.5 to 2 rounds: every CU holds a chunk that takes second pairs.  The nblk - C single-round chunks are the
+            // partners of the chunks with the longest two-round totals (shortest partner for the longest of them); the
+            // chunks with the shortest first-round pairs share their CUs among themselves.
+            const int Nn = nblk - C;
+            if (a < Nn) chunk = bb < Hh ? Nn - 1 - a : Nn + a;
+            else chunk = bb < Hh ? nblk - 1 - 2 * (a - Nn) : nblk - 2 - 2 * (a - Nn);
+        }
         first_idx = chunk * GPB + (int)(threadIdx.x >> 6) * (64 / G) + lane / G;
     }
 
