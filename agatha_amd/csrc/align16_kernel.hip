@@ -396,10 +396,22 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
     constexpr int GPB = 4 * (64 / G);                  // lane groups per workgroup
     const int nblk = (int)gridDim.x, cap = nblk * GPB;
     int chain_chunks = (La->n - cap + GPB - 1) / GPB;
-    const bool deal = (nblk == 2 * La->num_cus) && La->n >= cap && chain_chunks <= nblk && !La->no_deal;
+    const bool deal_full = (nblk == 2 * La->num_cus) && La->n > cap - GPB && chain_chunks <= nblk && !La->no_deal;
+    // Less than one round on more workgroups than CUs: the CUs that hold one workgroup take the longest chunks (a wave
+    // alone on its SIMD is the faster one), the others the shortest, again paired longest with shortest.
+    const bool deal_part = nblk > La->num_cus && nblk < 2 * La->num_cus && La->n <= cap && !La->no_deal;
+    const bool deal = deal_full || deal_part;
     bool first_round = deal;
     int first_idx = 0;
-    if (deal) {
+    if (deal_part) {
+        const int Hh = La->num_cus, D = nblk - Hh, bb = (int)blockIdx.x;
+        int chunk;
+        if (bb >= Hh) chunk = nblk - 1 - (bb - Hh);            // second workgroup of its CU: the shortest chunks
+        else if (bb < D) chunk = (Hh - D) + bb;                  // its partner: the longest of the 2 D shortest
+        else chunk = bb - D;                                     // alone on its CU: the longest chunks
+        first_idx = chunk * GPB + (int)(threadIdx.x >> 6) * (64 / G) + lane / G;
+    }
+    if (deal_full) {
         const int Hh = nblk / 2, C = chain_chunks, bb = (int)blockIdx.x;
         const int a = bb < Hh ? bb : bb - Hh;
         int chunk;
@@ -424,7 +436,7 @@ align16_kernel(const AlignLaunch* __restrict__ La, AlignParams Pm, int kid)
             int idx = 0;
             if (first_round) idx = first_idx;
             else {
-                if (need && k == 0) idx = (int)atomicAdd(La->queue + 0, 1u) + (deal ? cap : 0);
+                if (need && k == 0) idx = (int)atomicAdd(La->queue + 0, 1u) + (deal ? cap : 0);      // (deal_part: nothing is left)
                 idx = lane_read(idx, gbase);
             }
             first_round = false;

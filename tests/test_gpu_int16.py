@@ -230,12 +230,13 @@ def test_n_in_query_and_other_letters_are_routed(eng):
     assert _same(got, exp)
 
 
-@pytest.mark.parametrize("n", [8192, 8200, 9000, 12288, 12300, 15000, 16384, 16400])
+@pytest.mark.parametrize("n", [4100, 5000, 8000, 8185, 8192, 8200, 9000, 12288, 12300, 15000, 16384, 16400])
 def test_first_round_dealt_to_the_workgroups(eng, n):
     """With a full grid (8192 lane groups for a narrow band) and between 1 and 2 rounds of pairs the int16 kernel deals
     the first round to the workgroups by formula (which waves share a SIMD; two formulas, below and above 1.5 rounds)
     and takes the rest from the queue; pairs the kernel must skip (N in the query, other letters) sit in the dealt range
-    as well.  16 400 pairs: plain queue."""
+    as well.  16 400 pairs: plain queue.  Below one round, with more workgroups than CUs, everything is dealt (the CUs
+    with one workgroup take the longest chunks)."""
     rng = np.random.default_rng(n)
     qs, ts = [], []
     for k in range(n):
