@@ -204,18 +204,23 @@ __device__ __forceinline__ void row_cells4(uint32_t& t0, uint32_t& t1, uint32_t&
 __device__ __forceinline__ void row_keys4(int& a0, int& a1, int& a2, int& a3, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
                                           uint32_t kmul, int rowc_lo, int rowc_hi)
 {
-    int x, y;
-#define AGATHA16_KEY(A, H) \
-        "v_mad_u32_u16 %[x], " H ", %[km], %[rl]\n\t" \
-        "v_mad_u32_u16 %[y], " H ", %[km], %[rh] op_sel:[1,1,0,0]\n\t" \
-        "v_max3_i32 " A ", " A ", %[x], %[y]\n\t"
-    asm(AGATHA16_KEY("%[a0]", "%[h0]")
-        AGATHA16_KEY("%[a1]", "%[h1]")
-        AGATHA16_KEY("%[a2]", "%[h2]")
-        AGATHA16_KEY("%[a3]", "%[h3]")
-        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [x] "=&v"(x), [y] "=&v"(y)
+    int x, y, x2, y2;
+    // (the two multiply-adds of the next cell sit between a cell's multiply-adds and its v_max3: a lone wave does not issue
+    // a dependent instruction back to back without a bubble)
+    asm("v_mad_u32_u16 %[x], %[h0], %[km], %[rl]\n\t"
+        "v_mad_u32_u16 %[y], %[h0], %[km], %[rh] op_sel:[1,1,0,0]\n\t"
+        "v_mad_u32_u16 %[x2], %[h1], %[km], %[rl]\n\t"
+        "v_mad_u32_u16 %[y2], %[h1], %[km], %[rh] op_sel:[1,1,0,0]\n\t"
+        "v_max3_i32 %[a0], %[a0], %[x], %[y]\n\t"
+        "v_mad_u32_u16 %[x], %[h2], %[km], %[rl]\n\t"
+        "v_mad_u32_u16 %[y], %[h2], %[km], %[rh] op_sel:[1,1,0,0]\n\t"
+        "v_max3_i32 %[a1], %[a1], %[x2], %[y2]\n\t"
+        "v_mad_u32_u16 %[x2], %[h3], %[km], %[rl]\n\t"
+        "v_mad_u32_u16 %[y2], %[h3], %[km], %[rh] op_sel:[1,1,0,0]\n\t"
+        "v_max3_i32 %[a2], %[a2], %[x], %[y]\n\t"
+        "v_max3_i32 %[a3], %[a3], %[x2], %[y2]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [x] "=&v"(x), [y] "=&v"(y), [x2] "=&v"(x2), [y2] "=&v"(y2)
         : [h0] "v"(h0), [h1] "v"(h1), [h2] "v"(h2), [h3] "v"(h3), [km] "v"(kmul), [rl] "v"(rowc_lo), [rh] "v"(rowc_hi));
-#undef AGATHA16_KEY
 }
 
 // profile row of query class (bits shift+1..shift of the class word): v_bfe_u32 + v_lshl_add_u32 (laundered so that the
