@@ -3,6 +3,8 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -19,6 +21,27 @@ int hip_fail(hipError_t e, const char* what)
     return AGATHA_AMD_EHIP;
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+// Debug / A-B options (agatha_amd_set_debug_option).  Process-global, read with relaxed atomics on the hot path; the
+// environment variables AGATHA_AMD_<NAME> only give the initial values, read once.
+struct DebugOption { const char* name; const char* env; std::atomic<int> value; };
+DebugOption g_opts[] = {
+    {"max_blocks", "AGATHA_AMD_MAX_BLOCKS", {0}},      // > 0: cap of the persistent grids
+    {"no_deal", "AGATHA_AMD_NO_DEAL", {0}},            // 1: no dealt first round, every pair from the work queue
+    {"no_int16", "AGATHA_AMD_NO_INT16", {0}},          // 1: the packed-int16 kernel is not a candidate
+    {"force_int16", "AGATHA_AMD_FORCE_INT16", {0}},    // 1: ... is the only candidate (when the scores allow it)
+    {"force_choice", "AGATHA_AMD_FORCE_CHOICE", {-1}}, // >= 0: candidate index that takes the plain pairs
+    {"no_migrate", "AGATHA_AMD_NO_MIGRATE", {0}},      // 1: pairs never move between lane groups (no preemptive schedule)
+};
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_COUNT };
+std::once_flag g_opts_once;
+void init_opts()
+{
+    std::call_once(g_opts_once, [] {
+        for (DebugOption& o : g_opts) { const char* e = getenv(o.env); if (e && *e) o.value.store(atoi(e), std::memory_order_relaxed); }
+    });
+}
+int opt(int which) { init_opts(); return g_opts[which].value.load(std::memory_order_relaxed); }
 
 constexpr uint32_t kBuckets = 16384;     // sort buckets of 32 bases of (query + target) length
 constexpr size_t kAlign = 256;
@@ -142,18 +165,14 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.kind_counts = queue + 12;
     L.force_cmp = (sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     HIPCHK(agatha::launch_exotic(L, st));
-    { const char* e = getenv("AGATHA_AMD_MAX_BLOCKS"); L.max_blocks_override = e ? atoi(e) : 0; }
-    { const char* e = getenv("AGATHA_AMD_NO_DEAL"); L.no_deal = (e && atoi(e)) ? 1 : 0; }
+    L.max_blocks_override = opt(OPT_MAX_BLOCKS);
+    L.no_deal = opt(OPT_NO_DEAL) ? 1 : 0;
     // Candidates for the plain pairs: the packed-int16 kernel when the scores and the band allow it, the int32 kernel
     // in its throughput shape and in its latency shape; which one runs is decided on the device from the batch's length
-    // histogram (record_kernel).  AGATHA_AMD_NO_INT16=1 removes the int16 kernel, AGATHA_AMD_FORCE_INT16=1 makes it the
-    // only candidate (A/B runs, tests).
-    { const char* e = getenv("AGATHA_AMD_NO_INT16");
-      const char* f = getenv("AGATHA_AMD_FORCE_INT16");
-      const char* c = getenv("AGATHA_AMD_FORCE_CHOICE");
-      L.force_choice = c ? atoi(c) : -1;
-      L.choice = choice; L.totals = totals;
-      HIPCHK(agatha::plan_align(L, (int)window, e && atoi(e), f && atoi(f))); }
+    // histogram (record_kernel).  Debug options no_int16 / force_int16 / force_choice override it (A/B runs, tests).
+    L.force_choice = opt(OPT_FORCE_CHOICE);
+    L.choice = choice; L.totals = totals;
+    HIPCHK(agatha::plan_align(L, (int)window, opt(OPT_NO_INT16) != 0, opt(OPT_FORCE_INT16) != 0));
     g_last16 = (L.ncand > 0 && L.cand[0].kind == 1) ? ((L.cand[0].G << 8) | L.cand[0].S) : 0;
     L.self_dev = rec;
     HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record, queue head reset, kernel choice; stream-ordered
@@ -161,6 +180,24 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st));
     if (g_ev1) HIPCHK(hipEventRecord(g_ev1, st));
     return 0;
+}
+
+int agatha_amd_set_debug_option(const char* name, int value)
+{
+    if (!name) return AGATHA_AMD_EINVAL;
+    init_opts();
+    for (DebugOption& o : g_opts)
+        if (strcmp(o.name, name) == 0) { o.value.store(value, std::memory_order_relaxed); return 0; }
+    return AGATHA_AMD_EINVAL;
+}
+
+int agatha_amd_get_debug_option(const char* name, int* value)
+{
+    if (!name || !value) return AGATHA_AMD_EINVAL;
+    init_opts();
+    for (DebugOption& o : g_opts)
+        if (strcmp(o.name, name) == 0) { *value = o.value.load(std::memory_order_relaxed); return 0; }
+    return AGATHA_AMD_EINVAL;
 }
 
 void agatha_amd_set_kernel_events(void* ev_begin, void* ev_end) { g_ev0 = (hipEvent_t)ev_begin; g_ev1 = (hipEvent_t)ev_end; }

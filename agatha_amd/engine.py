@@ -75,6 +75,8 @@ def load_library():
     lib.agatha_amd_last_config.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.agatha_amd_last_config.restype = None
     lib.agatha_amd_last_int16_config.restype = C.c_int
+    lib.agatha_amd_set_debug_option.argtypes = [C.c_char_p, C.c_int]
+    lib.agatha_amd_get_debug_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
     lib.agatha_amd_pair_kinds.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.agatha_amd_kernel_choice.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -98,12 +100,43 @@ def load_library():
 EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack",
-    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
     "agatha_amd_event_destroy", "agatha_amd_event_record", "agatha_amd_event_elapsed_ms",
 ]
+
+
+def set_debug_option(name, value):
+    """Routing knobs of agatha_amd_align for tests and A/B runs (include/agatha_amd.h: agatha_amd_set_debug_option)."""
+    lib = load_library()
+    _chk(lib, lib.agatha_amd_set_debug_option(name.encode(), int(value)))
+
+
+def get_debug_option(name):
+    lib = load_library()
+    v = C.c_int(0)
+    _chk(lib, lib.agatha_amd_get_debug_option(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
+class debug_options:
+    """with debug_options(force_int16=1): ...   -- sets the options, restores the previous values on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_debug_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_debug_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_debug_option(k, v)
+        return False
 
 
 def _chk(lib, rc):

@@ -4,13 +4,14 @@
 //          [-n host_threads] [-p] <file1.fasta> <file2.fasta> [rawlog if -p]
 // Options are scanned over argv[1 .. argc-4]; the last two (three with -p) arguments are positional; argc < 4 is
 // refused; unknown single letters are ignored.  -b/-t are accepted and ignored by the HIP engine (its launch shape
-// is derived from the band); -c (extension) enables the reverse/complement op codes of the FASTA headers.
+// is derived from the band); -c (extension) enables the reverse/complement op codes of the FASTA headers; -g N
+// (extension) spreads the host threads over N GPUs.
 #include "../../include/gasal_header.h"
 
 Parameters::Parameters(int argc_, char** argv_)
     : sa(2), sb(4), gapo(4), gape(2), print_out(0), n_threads(1), slice_width(3), z_threshold(400), band_width(751),
       kernel_block_num(256), kernel_thread_num(256), kernel_align_num(8192), isPacked(false),
-      isReverseComplement(false), argc(argc_), argv(argv_)
+      isReverseComplement(false), n_gpus(1), argc(argc_), argv(argv_)
 {
 }
 
@@ -66,6 +67,7 @@ void Parameters::help()
     std::cerr << "         -p        print the alignment results; append kernel ms per batch to raw.log" << std::endl;
     std::cerr << "         -n INT    number of CPU threads [" << n_threads << "]" << std::endl;
     std::cerr << "         -c        apply the reverse/complement codes of the FASTA header characters (> < / +)" << std::endl;
+    std::cerr << "         -g INT    spread the CPU threads over this many GPUs [" << n_gpus << "]" << std::endl;
     std::cerr << "         --help, -h : displays this message." << std::endl;
     std::cerr << "Single-pack multi-Parameters (e.g. -sp) is not supported." << std::endl;
 }
@@ -93,6 +95,7 @@ void Parameters::parse()
             case 'p': print_out = 1; break;
             case 'c': isReverseComplement = true; break;
             case 'n': n_threads = next_int(c); break;
+            case 'g': n_gpus = next_int(c); break;
             case 's': slice_width = next_int(c); break;
             case 'z': z_threshold = next_int(c); break;
             case 'w': band_width = next_int(c); break;

@@ -12,10 +12,14 @@
 #include "../../include/agatha_amd.h"
 
 #include <algorithm>
+#include <mutex>
 
 namespace {
 
+// Process-global like the reference's __constant__ symbols (gasal_kernels.h:29-36): set it once, before any thread
+// aligns; gasal_aln_async reads it unsynchronised.
 gasal_subst_scores g_scores = {2, 4, 4, 2, 3, 400, 751};    // defaults of args_parser.cpp:12-22
+std::mutex g_raw_mutex;                                     // serialises the -p lines of concurrent host threads
 
 [[noreturn]] void die_hip(int rc, int line)
 {
@@ -409,7 +413,7 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
         exit(EXIT_FAILURE);
     }
     CHK(rc);
-    if (params->print_out) { CHK(agatha_amd_event_record(s->ev_end, s->str)); s->timing_pending = 1; }
+    if (params->print_out) { CHK(agatha_amd_event_record(s->ev_end, s->str)); s->timing_pending = 1; s->timing_params = params; }
 
     const size_t rb = (size_t)actual_n_alns * sizeof(int32_t);      // gasal_align.cu:253-266
     CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->aln_score, s->device_cpy->aln_score, rb));
@@ -425,16 +429,19 @@ int gasal_is_aln_async_done(gasal_gpu_storage_t* s)
     const int q = agatha_amd_stream_query(s->str);
     if (q == 1) return -1;
     if (q < 0) die_hip(q, __LINE__);
+    // -p: the library itself appends the batch's kernel milliseconds to params->raw_file, as the reference does inside
+    // gasal_aln_async (gasal_align.cu:218-236).  The reference blocks there (cudaDeviceSynchronize); here the call stays
+    // asynchronous and the line is written when the batch is seen to be complete.
+    if (s->timing_pending) {
+        float ms = 0.f;
+        CHK(agatha_amd_event_elapsed_ms(s->ev_begin, s->ev_end, &ms));
+        Parameters* p = (Parameters*)s->timing_params;
+        if (p) { std::lock_guard<std::mutex> lock(g_raw_mutex); p->raw_file << ms << std::endl; }
+        s->timing_pending = 0;
+        s->timing_params = nullptr;
+    }
     gasal_host_batch_reset(s);
     s->is_free = 1;
     s->current_n_alns = 0;
     return 0;
-}
-
-// extension used by the CLI's -p mode: kernel milliseconds of the batch that just completed (one line of the raw log)
-extern "C" float agatha_gasal_last_batch_ms(gasal_gpu_storage_t* s)
-{
-    float ms = 0.f;
-    if (s->timing_pending) { CHK(agatha_amd_event_elapsed_ms(s->ev_begin, s->ev_end, &ms)); s->timing_pending = 0; }
-    return ms;
 }

@@ -6,7 +6,10 @@
 // batches of -a alignments, each batch goes through gasal_host_batch_fill + gasal_aln_async on one of
 // NB_STREAMS storages per host thread; with -p every pair prints
 //     <score>\tquery_batch_end=<q>\ttarget_batch_end=<t>
-// in input order within a batch, and one kernel-milliseconds line per batch is appended to the raw log.
+// in input order within a batch; the library appends one kernel-milliseconds line per batch to the raw log
+// (gasal_is_aln_async_done, as the reference's gasal_aln_async does: gasal_align.cu:218-236).  -g N (extension) spreads
+// the host threads over N GPUs with gasal_set_device (interfaces.cpp:86-116, the call the reference leaves commented
+// out at test_prog.cpp:31).
 // Own reader (each file is parsed on its own, so records with different line counts stay in step).
 #include "../../include/gasal_header.h"
 
@@ -16,8 +19,6 @@
 #include <vector>
 
 #define NB_STREAMS 2
-
-extern "C" float agatha_gasal_last_batch_ms(gasal_gpu_storage_t* s);
 
 struct FastaSet {
     std::vector<std::string> seqs;
@@ -89,7 +90,9 @@ int main(int argc, char** argv)
 
     omp_set_num_threads(n_threads);
     std::vector<gasal_gpu_storage_v> vecs(n_threads);
+    const int n_gpus = args->n_gpus > 0 ? args->n_gpus : 1;
     for (int t = 0; t < n_threads; t++) {
+        if (n_gpus > 1) gasal_set_device(t % n_gpus, false);      // this thread's buffers and streams live on its GPU
         vecs[t] = gasal_init_gpu_storage_v(NB_STREAMS);
         gasal_init_streams(&vecs[t], (int)max_q + 7, (int)max_t + 7, (int32_t)maximum_sequence_length, args);
     }
@@ -97,6 +100,7 @@ int main(int argc, char** argv)
 #pragma omp parallel
     {
         const int tid = omp_get_thread_num();
+        if (n_gpus > 1) gasal_set_device(tid % n_gpus, false);
         const int n_seqs = thread_count[tid];
         const int n_batches = (int)ceil((double)n_seqs / args->kernel_align_num);
         int next = thread_first[tid], seqs_done = 0, batches_done = 0;
@@ -136,7 +140,6 @@ int main(int argc, char** argv)
                             for (int j = 0; j < slot[z].n; j++)
                                 std::cout << r->aln_score[j] << "\tquery_batch_end=" << r->query_batch_end[j]
                                           << "\ttarget_batch_end=" << r->target_batch_end[j] << std::endl;
-                            if (args->raw_file.is_open()) args->raw_file << agatha_gasal_last_batch_ms(slot[z].st) << std::endl;
                         }
                     }
                     batches_done++;
@@ -146,6 +149,7 @@ int main(int argc, char** argv)
     }
 
     for (int t = 0; t < n_threads; t++) {
+        if (n_gpus > 1) gasal_set_device(t % n_gpus, false);
         gasal_destroy_streams(&vecs[t], args);
         gasal_destroy_gpu_storage_v(&vecs[t]);
     }

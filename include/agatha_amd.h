@@ -96,9 +96,19 @@ void agatha_amd_last_config(int* lanes_per_pair, int* slots_per_lane);
 
 /* (lanes_per_pair << 8) | slots_per_lane of the packed-int16 kernel if it was a CANDIDATE in the last
  * agatha_amd_align() of this thread (scores and band inside its domain), 0 if not.  Whether it ran is the device's
- * choice (agatha_amd_kernel_choice).  Environment: AGATHA_AMD_NO_INT16=1 removes it from the candidates,
- * AGATHA_AMD_FORCE_INT16=1 makes it the only one. */
+ * choice (agatha_amd_kernel_choice); debug options no_int16 / force_int16 below override it. */
 int agatha_amd_last_int16_config(void);
+
+/* Debug / A-B options of the routing inside agatha_amd_align (never needed for correct results; tests and the tuning
+ * tools use them).  Process-global; the environment variable AGATHA_AMD_<NAME IN CAPITALS> gives the initial value and
+ * is read ONCE, at the first use of the library -- the hot path never calls getenv.  Names:
+ *   "no_int16" (1: the packed-int16 kernel is not a candidate), "force_int16" (1: it is the only candidate when the
+ *   scores and the band allow it), "force_choice" (>= 0: index of the candidate that takes the plain pairs, -1 = model),
+ *   "no_deal" (1: no dealt first round), "no_migrate" (1: pairs never move between lane groups), "max_blocks"
+ *   (> 0: cap of the persistent grids).
+ * Returns AGATHA_AMD_EINVAL for an unknown name. */
+int agatha_amd_set_debug_option(const char* name, int value);
+int agatha_amd_get_debug_option(const char* name, int* value);
 
 /* Diagnostics: which candidate kernel the device chose for the plain pairs of the last agatha_amd_align() on this
  * workspace: out[0] = 0 int32 profile kernel / 1 packed-int16 kernel, out[1] = lanes per pair, out[2] = slots per lane.

@@ -116,6 +116,7 @@ typedef struct {
     void* ev_begin;                     /* hipEvent_t pair for the -p timing mode */
     void* ev_end;
     int timing_pending;
+    void* timing_params;                /* Parameters* of the batch in flight: its raw_file gets the -p line */
     int is_free;
     int id;
 } gasal_gpu_storage_t;
@@ -145,6 +146,7 @@ class Parameters {
     int32_t kernel_block_num, kernel_thread_num, kernel_align_num;
     bool isPacked;
     bool isReverseComplement;
+    int n_gpus;                         /* extension (-g): host threads are spread over this many GPUs (gasal_set_device) */
     std::string query_batch_fasta_filename, target_batch_fasta_filename, raw_filename;
     std::ifstream query_batch_fasta, target_batch_fasta;
     std::ofstream raw_file;

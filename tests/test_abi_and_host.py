@@ -93,3 +93,34 @@ def test_avg_time_contract(tmp_path):
     avg_time.main(["AGAThA", "empty", str(tmp_path / "empty.log"), str(out), "3"])
     avg_time.main(["other", "gone", str(tmp_path / "missing.log"), str(out), "3"])
     assert json.loads(out.read_text()) == {"AGAThA": {"test": 4.0, "empty": "NaN"}, "other": {"gone": "NaN"}}
+
+
+REF_CLIENT_SRC = "/root/reference/AGAThA/test_prog/test_prog.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLIENT_SRC), reason="reference tree absent (build container only)")
+def test_reference_client_builds_against_this_boundary(tmp_path):
+    """The reference's OWN client (AGAThA/test_prog/test_prog.cpp) compiles against include/ and links libgasal_amd.so
+    with exactly ONE documented edit: its line 25, a bare cudaDeviceSynchronize() -- a CUDA
+    runtime name the reference's gasal.h:8 drags in and this library does not provide -- is dropped.  Unedited it must
+    fail on that name and on nothing else.  (`make -C oracle ref` builds the same binary into oracle/_ref/ for the GPU
+    half of this check, tests/test_gpu_cli.py.)"""
+    src = open(REF_CLIENT_SRC).read()
+    assert src.count("cudaDeviceSynchronize();") == 1 and "cuda" not in src.replace("cudaDeviceSynchronize();", "").lower()
+    base = ["g++", "-O1", "-std=c++17", "-fopenmp", "-w", "-I" + os.path.join(ROOT, "include"),
+            "-I" + os.path.dirname(REF_CLIENT_SRC)]
+    link = ["-L" + os.path.join(ROOT, "agatha_amd"), "-lgasal_amd", "-lagatha_amd",
+            "-Wl,-rpath," + os.path.join(ROOT, "agatha_amd")]
+    # (a) unchanged: one error, the CUDA runtime name
+    r = subprocess.run(base + ["-fsyntax-only", REF_CLIENT_SRC], capture_output=True, text=True)
+    errors = [l for l in r.stderr.splitlines() if "error:" in l]
+    assert r.returncode != 0 and len(errors) == 1 and "cudaDeviceSynchronize" in errors[0], r.stderr
+    # (b) with the documented edit: compiles, links, and honours the argument contract without a GPU
+    edited = tmp_path / "ref_test_prog.cpp"
+    edited.write_text("\n".join(l for l in src.split("\n") if l.strip() != "cudaDeviceSynchronize();"))
+    exe = tmp_path / "ref_test_prog"
+    r = subprocess.run(base + ["-o", str(exe), str(edited)] + link, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), "a.fa", "b.fa"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Not enough" in r.stderr
+    edited.unlink()          # no reference text stays behind, not even under pytest's tmp dir

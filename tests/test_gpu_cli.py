@@ -30,6 +30,18 @@ def parse(out):
     return np.array(res, np.int64)
 
 
+def match_batches(got, batches):
+    """Lines are in input order inside a batch; batches are printed in the order their streams are seen to finish (two
+    streams per host thread, exactly as the reference's test_prog.cpp:355-374), so match batch by batch."""
+    pos, unused = 0, list(range(len(batches)))
+    while pos < len(got):
+        hit = [k for k in unused if (got[pos:pos + len(batches[k])] == batches[k]).all()]
+        assert hit, f"printed block at line {pos} matches no batch"
+        pos += len(batches[hit[0]])
+        unused.remove(hit[0])
+    assert not unused
+
+
 @pytest.mark.parametrize("threads,align_num", [(1, 8192), (1, 100), (3, 64)])
 def test_cli_matches_oracle(tmp_path, threads, align_num):
     qs, ts = synth.cfg_c4(n=300, seed=99, lo=100, hi=4000)
@@ -51,13 +63,7 @@ def test_cli_matches_oracle(tmp_path, threads, align_num):
     for t in range(threads):
         lo, hi = t * per_thread, min(300, (t + 1) * per_thread)
         batches += [exp[k:min(k + align_num, hi)] for k in range(lo, hi, align_num)]
-    pos, unused = 0, list(range(len(batches)))
-    while pos < len(got):
-        hit = [k for k in unused if (got[pos:pos + len(batches[k])] == batches[k]).all()]
-        assert hit, f"printed block at line {pos} matches no batch"
-        pos += len(batches[hit[0]])
-        unused.remove(hit[0])
-    assert not unused
+    match_batches(got, batches)
     lines = open(raw).read().split()
     n_batches = sum(-(-c // align_num) for c in ([300] if threads == 1 else [100, 100, 100]))
     assert len(lines) == n_batches and all(float(x) > 0 for x in lines)
@@ -110,3 +116,37 @@ def test_multi_gpu_front_end_single_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     exp = np.stack(O.align_pairs(qs, ts, O.make_params(m=1, x=4, q=6, r=2, s=3, z=100, w=100), wide=True, threads=4), axis=1)
     assert (parse(r.stdout) == exp).all()
+
+
+REF_CLIENT = os.path.join(ROOT, "oracle", "_ref", "ref_test_prog")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLIENT), reason="oracle/_ref/ref_test_prog not built (make -C oracle ref, build container)")
+def test_reference_client_and_manual_behave_alike(tmp_path):
+    """Drop-in check of the GASAL boundary with the reference's OWN client: AGAThA/test_prog/test_prog.cpp, compiled in the
+    build container against include/ + libgasal_amd.so (one documented edit, tests/test_abi_and_host.py), and this repo's
+    `manual` print the same score.log on the C0 stand-in and the library writes one raw.log line per batch for both
+    (the reference writes that line inside gasal_aln_async, gasal_align.cu:218-236)."""
+    qs, ts = synth.cfg_c0(n=600)
+    f1, f2 = tmp_path / "ref.fasta", tmp_path / "query.fasta"
+    # the reference client reads its two files in line lock-step (test_prog.cpp:94): one line per record
+    write_fasta(f1, qs, width=10 ** 9, header=">")
+    write_fasta(f2, ts, width=10 ** 9, header=">")
+    flags = ["-p", "-m", "1", "-x", "4", "-q", "6", "-r", "2", "-s", "3", "-z", "400", "-w", "751"]      # AGAThA.sh:44
+    exp = np.stack(O.align_pairs(qs, ts, O.make_params(m=1, x=4, q=6, r=2, s=3, z=400, w=751), wide=True, threads=4), axis=1)
+    for align_num, n_batches in ((8192, 1), (250, 3)):
+        outs = {}
+        for name, exe in (("manual", MANUAL), ("reference_client", REF_CLIENT)):
+            raw = tmp_path / f"raw_{name}_{align_num}.log"
+            r = subprocess.run([exe] + flags + ["-a", str(align_num), str(f1), str(f2), str(raw)], capture_output=True,
+                               text=True, timeout=600)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+            lines = open(raw).read().split()
+            assert len(lines) == n_batches and all(float(x) > 0 for x in lines), (name, lines)
+            outs[name] = r.stdout
+        if n_batches == 1:
+            assert outs["manual"] == outs["reference_client"]                      # score.log, byte for byte
+            assert (parse(outs["manual"]) == exp).all()
+        else:
+            for o in outs.values():
+                match_batches(parse(o), [exp[k:k + align_num] for k in range(0, 600, align_num)])

@@ -16,18 +16,18 @@ BASE = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
 @pytest.fixture(scope="module")
 def eng():
     import agatha_amd
-    os.environ["AGATHA_AMD_FORCE_INT16"] = "1"      # the launcher leaves small batches to the int32 kernel otherwise
+    agatha_amd.set_debug_option("force_int16", 1)      # the launcher leaves small batches to the int32 kernel otherwise
     e = agatha_amd.Engine(0)
     yield e
     e.close()
-    del os.environ["AGATHA_AMD_FORCE_INT16"]
+    agatha_amd.set_debug_option("force_int16", 0)
 
 
 def test_device_side_kernel_choice(eng):
     """Without the override the device picks the kernel from the length histogram: a small batch is latency-bound (64
     lanes per pair, one register pair per lane), a large uniform one throughput-bound (16 lanes per pair, three)."""
     import agatha_amd
-    del os.environ["AGATHA_AMD_FORCE_INT16"]
+    agatha_amd.set_debug_option("force_int16", 0)
     try:
         for n, expect in ((64, ("int16", 64, 2)), (9000, ("int16", 16, 6))):
             qs, ts = WL.make_pairs(3, n, lambda r: int(r.integers(900, 1100)), 0.03, 0.03, 0.04)
@@ -40,7 +40,7 @@ def test_device_side_kernel_choice(eng):
             finally:
                 b.free()
     finally:
-        os.environ["AGATHA_AMD_FORCE_INT16"] = "1"
+        agatha_amd.set_debug_option("force_int16", 1)
 
 
 def _run(eng, qs, ts, p):
@@ -133,12 +133,12 @@ def test_int16_and_int32_kernels_agree(eng):
     sc = agatha_amd.Scores.make(**BASE)
     a = eng.align_host_batch(qb, tb, qo, to, ql, tl, sc)
     assert eng.last_int16_config() == (16, 6)
-    os.environ["AGATHA_AMD_NO_INT16"] = "1"
+    agatha_amd.set_debug_option("no_int16", 1)
     try:
         b = eng.align_host_batch(qb, tb, qo, to, ql, tl, sc)
         assert eng.last_int16_config() is None
     finally:
-        del os.environ["AGATHA_AMD_NO_INT16"]
+        agatha_amd.set_debug_option("no_int16", 0)
     assert _same(a, b)
 
 
@@ -251,11 +251,11 @@ def test_first_round_dealt_to_the_workgroups(eng, n):
             rd[rng.integers(0, rd.size)] = ord("R")            # other letter: compare kernel
         qs.append(ref.tobytes()); ts.append(rd.tobytes())
     p = dict(BASE, w=24)
-    os.environ["AGATHA_AMD_FORCE_CHOICE"] = "0"                # the int16 throughput shape <16,1>: 16 groups per workgroup
+    agatha_amd.set_debug_option("force_choice", 0)             # the int16 throughput shape <16,1>: 16 groups per workgroup
     try:
         got, exp, kinds = _run_with_kinds(eng, qs, ts, p)
     finally:
-        del os.environ["AGATHA_AMD_FORCE_CHOICE"]
+        agatha_amd.set_debug_option("force_choice", -1)
     assert _same(got, exp)
     assert int(kinds[1]) > 0 and int(kinds[2]) > 0
 

@@ -13,8 +13,7 @@ for name, gen, p in (("C3", lambda: synth.cfg_c3(n=256), dict(m=2, x=4, q=4, r=2
     b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); eng.synchronize()
     sc = agatha_amd.Scores.make(**p)
     for c in ("", "0", "1", "2", "3"):
-        if c: os.environ["AGATHA_AMD_FORCE_CHOICE"] = c
-        elif "AGATHA_AMD_FORCE_CHOICE" in os.environ: del os.environ["AGATHA_AMD_FORCE_CHOICE"]
+        agatha_amd.set_debug_option("force_choice", int(c) if c else -1)
         ms = []
         for rep in range(2):
             e0, e1 = eng.event(), eng.event(); eng.record(e0); b.align(sc); eng.record(e1); ms.append(eng.elapsed_ms(e0, e1))

@@ -47,12 +47,9 @@ while time.time() < t_end:
         qs.append(ref.tobytes()); ts.append(rd.tobytes())
     qb, qo, ql = WL.make_batch(qs); tb, to, tl = WL.make_batch(ts)
     exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=16)
-    for mode, env in (("choice", {}), ("int16", {"AGATHA_AMD_FORCE_INT16": "1"}), ("int32", {"AGATHA_AMD_NO_INT16": "1"})):
-        for k_, v_ in env.items(): os.environ[k_] = v_
-        try:
+    for mode, opts in (("choice", {}), ("int16", {"force_int16": 1}), ("int32", {"no_int16": 1})):
+        with agatha_amd.debug_options(**opts):
             got = eng.align_host_batch(qb, tb, qo, to, ql, tl, agatha_amd.Scores.make(**p), use_len_hint=bool(rng.integers(0, 2)))
-        finally:
-            for k_ in env: del os.environ[k_]
         diff = [i for i in range(len(ql)) if any(int(exp[j][i]) != int(got[j][i]) for j in range(3))]
         if diff:
             bad += 1
