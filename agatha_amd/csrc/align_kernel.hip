@@ -708,6 +708,61 @@ hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Preemptive static schedule for the packed-int16 throughput shape (the reference's subwarp rejoining,
+// agatha_kernel.h:365-408, re-derived for independent lane groups: instead of idle lanes joining a pair in flight, pairs
+// in flight move to lane groups that would otherwise idle).  With n pairs on m < n lane groups and every pair's step count
+// p_j known from its lengths, McNaughton's wrap-around rule gives the optimal preemptive makespan T = max(p_max,
+// ceil(sum p_j / m)): the pairs are laid end to end (sorted order) on a line, lane group s owns [s T, (s+1) T).  A pair
+// that crosses a boundary b T is split: group b runs its FIRST steps at the start of its life and suspends it (state ->
+// HBM), group b - 1 resumes it at the end of its own; p_j <= T keeps the two parts apart in time.  This kernel computes the
+// step counts (0 for pairs the int16 kernel skips), their prefix sums and T, and decides whether the schedule is used.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+schedule_kernel(AlignLaunch L, int GS)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t pmaxs[1024];
+    const int n = L.n, m = L.mig_slots, t = threadIdx.x;
+    if (!L.mig_enabled || m <= 0 || n <= m || (long long)n > 8ll * m) { if (t == 0) L.sched[0] = 0; return; }
+    const int W = (L.p.band_width + 7) >> 3, sw = L.p.slice_width;
+    const int chunk = (n + 1023) / 1024;
+    const int j0 = t * chunk, j1 = min(n, j0 + chunk);
+    auto steps_of = [&](int j) -> uint32_t {
+        const uint32_t pair = L.order[j];
+        if (L.exotic[pair] != 0) return 0u;                 // another kernel's pair: skipped when drawn
+        const int Q = (int)L.qlens[pair], R = (int)L.tlens[pair];
+        const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
+        if (Q <= 0 || R <= 0 || min(W + 1, min(pql, prl)) > GS || pql + GS >= 32760 || prl + GS >= 32760) return 1u;
+        const int total = pql + prl - 1;
+        return (uint32_t)(((total + sw - 1) / sw) * sw + 2);  // dry step + whole slices + the final check step
+    };
+    uint32_t sum = 0, mx = 0;
+    for (int j = j0; j < j1; j++) { const uint32_t p = steps_of(j); sum += p; mx = max(mx, p); }
+    part[t] = sum; pmaxs[t] = mx;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0, pm = 0;
+        for (int k = 0; k < 1024; k++) { const uint32_t v = part[k]; part[k] = acc; acc += v; pm = max(pm, pmaxs[k]); }
+        const long long P = acc;
+        long long T = (P + m - 1) / m; if (T < (long long)pm) T = pm; if (T < 1) T = 1;
+        L.cum[n] = acc;
+        const bool use = pm > 0 && P <= 4ll * m * (long long)pm && P < (1ll << 30);
+        L.sched[0] = use ? 1 : 0; L.sched[1] = (int)T; L.sched[2] = (int)((P + T - 1) / T);
+    }
+    __syncthreads();
+    uint32_t acc = part[t];
+    for (int j = j0; j < j1; j++) { L.cum[j] = acc; acc += steps_of(j); }
+}
+
+hipError_t launch_schedule(const AlignLaunch& L, hipStream_t st)
+{
+    if (!L.mig_enabled) return hipSuccess;
+    const KernelChoice& k = L.cand[0];
+    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, st, L, k.G * k.S);
+    return hipGetLastError();
+}
+
 hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint32_t* hist, uint32_t nbuckets,
                        uint32_t* order, float* totals, hipStream_t st)
 {

@@ -2,6 +2,8 @@
 #include "../../include/agatha_amd.h"
 #include "kernels.h"
 
+#include <immintrin.h>
+
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -32,8 +34,13 @@ DebugOption g_opts[] = {
     {"force_int16", "AGATHA_AMD_FORCE_INT16", {0}},    // 1: ... is the only candidate (when the scores allow it)
     {"force_choice", "AGATHA_AMD_FORCE_CHOICE", {-1}}, // >= 0: candidate index that takes the plain pairs
     {"no_migrate", "AGATHA_AMD_NO_MIGRATE", {0}},      // 1: pairs never move between lane groups (no preemptive schedule)
+    {"mig_timeout_us", "AGATHA_AMD_MIG_TIMEOUT_US", {50000}},   // wait for a suspended pair this long, then take it over
+    {"mig_test_delay_us", "AGATHA_AMD_MIG_TEST_DELAY_US", {0}}, // tests: odd lane groups start this late
+    {"prio_slice", "AGATHA_AMD_PRIO_SLICE", {-1}},     // > 0: SIMD partners alternate issue priority every 2^n ticks (10 ns each); -1: 2^15 on a static schedule, off otherwise; 0: off
+    {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {8}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured
+    {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -58,6 +65,20 @@ int num_cus()
         cached_dev = dev;
     }
     return cached;
+}
+
+// Batches of more pairs than this can be larger than one round of the packed-int16 kernel's lane groups: their workspace
+// also holds the areas of the preemptive schedule (prefix sums, boundary states, suspended pair state: ~68 MiB).
+constexpr uint32_t kMigMinPairs = 4096;
+size_t base_workspace_bytes(uint32_t n)
+{
+    return round_up(sizeof(uint32_t) * (size_t)n) + round_up(sizeof(uint32_t) * kBuckets) + kAlign +
+           round_up(sizeof(agatha::AlignLaunch)) + round_up((size_t)n);
+}
+size_t mig_workspace_bytes(uint32_t n)
+{
+    return round_up(sizeof(uint32_t) * ((size_t)n + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) +
+           round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords) + agatha::kMigBufBytes;
 }
 
 }  // namespace
@@ -91,14 +112,49 @@ int agatha_amd_max_band(void) { return (agatha::max_window_blocks() - 1) * 8; }
 
 size_t agatha_amd_workspace_bytes(uint32_t max_n_alns)
 {
-    return round_up(sizeof(uint32_t) * (size_t)max_n_alns) + round_up(sizeof(uint32_t) * kBuckets) + kAlign +
-           round_up(sizeof(agatha::AlignLaunch)) + round_up((size_t)max_n_alns);
+    return base_workspace_bytes(max_n_alns) + (max_n_alns > kMigMinPairs ? mig_workspace_bytes(max_n_alns) : 0);
 }
 
 int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, uint32_t* d_packed)
 {
     if (!d_unpacked || !d_packed || nbytes == 0 || (nbytes % 8) != 0) return AGATHA_AMD_EINVAL;
     HIPCHK(agatha::launch_pack(d_unpacked, nbytes, d_packed, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- host-side packing (for pre-packed batches: halves the H2D bytes; reference ctors.cpp:65-73, gasal_align.cu:174) ----
+static void pack_host_scalar(const uint8_t* a, size_t nbytes, uint32_t* out)
+{
+    for (size_t w = 0; w < nbytes / 8; w++) {
+        uint32_t v = 0;
+        for (int k = 0; k < 8; k++) v |= (uint32_t)(a[8 * w + k] & 15u) << (28 - 4 * k);      // pack_rc_seqs.h:21-33
+        out[w] = v;
+    }
+}
+
+__attribute__((target("avx2"))) static void pack_host_avx2(const uint8_t* a, size_t nbytes, uint32_t* out)
+{
+    // 64 bases -> 8 words per iteration: low nibbles, pairs combined with one multiply-add (16 * even + odd), 16-bit sums
+    // narrowed to bytes, bytes of every word reversed (the first base sits in the word's top nibble)
+    const __m256i lo4 = _mm256_set1_epi8(0x0F), coef = _mm256_set1_epi16(0x0110);
+    const __m256i rev = _mm256_setr_epi8(3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9, 8, 15, 14, 13, 12, 3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9, 8, 15, 14, 13, 12);
+    size_t i = 0;
+    for (; i + 64 <= nbytes; i += 64) {
+        const __m256i v0 = _mm256_and_si256(_mm256_loadu_si256((const __m256i*)(a + i)), lo4);
+        const __m256i v1 = _mm256_and_si256(_mm256_loadu_si256((const __m256i*)(a + i + 32)), lo4);
+        const __m256i p0 = _mm256_maddubs_epi16(v0, coef), p1 = _mm256_maddubs_epi16(v1, coef);
+        __m256i b = _mm256_permute4x64_epi64(_mm256_packus_epi16(p0, p1), 0xD8);      // undo the per-lane interleave of packus
+        _mm256_storeu_si256((__m256i*)(out + i / 8), _mm256_shuffle_epi8(b, rev));
+    }
+    pack_host_scalar(a + i, nbytes - i, out + i / 8);
+}
+
+int agatha_amd_pack_host(const uint8_t* h_unpacked, size_t nbytes, uint32_t* h_packed)
+{
+    if (!h_unpacked || !h_packed || (nbytes % 8) != 0) return AGATHA_AMD_EINVAL;
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2) pack_host_avx2(h_unpacked, nbytes, h_packed);
+    else pack_host_scalar(h_unpacked, nbytes, h_packed);
     return 0;
 }
 
@@ -122,7 +178,7 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
         return AGATHA_AMD_EINVAL;
     if (n_alns == 0 || n_alns > 0x7fffffffu) return AGATHA_AMD_EINVAL;
     if (sc->slice_width < 1 || sc->band_width < 0 || sc->gap_extend < 0) return AGATHA_AMD_EINVAL;
-    if (workspace_bytes < agatha_amd_workspace_bytes(n_alns)) return AGATHA_AMD_EWORKSPACE;
+    if (workspace_bytes < base_workspace_bytes(n_alns)) return AGATHA_AMD_EWORKSPACE;
 
     // blocks that can be live on one block-anti-diagonal: min(W + 1, ceil(Q/8), ceil(R/8))
     const long W = ((long)sc->band_width + 7) / 8;
@@ -146,7 +202,14 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     uint32_t* hist = (uint32_t*)ws;              ws += round_up(sizeof(uint32_t) * kBuckets);
     unsigned int* queue = (unsigned int*)ws;     ws += kAlign;
     agatha::AlignLaunch* rec = (agatha::AlignLaunch*)ws;   ws += round_up(sizeof(agatha::AlignLaunch));
-    uint8_t* exotic = (uint8_t*)ws;
+    uint8_t* exotic = (uint8_t*)ws;                          ws += round_up((size_t)n_alns);
+    // areas of the preemptive schedule, present when the caller sized the workspace for a batch this large
+    const bool mig = n_alns > kMigMinPairs && workspace_bytes >= base_workspace_bytes(n_alns) + mig_workspace_bytes(n_alns) &&
+                     !opt(OPT_NO_MIGRATE);
+    uint32_t* cum = (uint32_t*)ws;                           ws += round_up(sizeof(uint32_t) * ((size_t)n_alns + 1));
+    int* mig_state = (int*)ws;                               ws += round_up(sizeof(int) * (agatha::kMigMaxSlots + 1));
+    uint32_t* timeline = (uint32_t*)ws;                      ws += round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords);
+    uint32_t* mig_buf = (uint32_t*)ws;
 
     // inside the 256-byte queue block: [0..3] queue heads, [8] step totals, [10] kernel choice, [12] pair-kind counters
     float* totals = (float*)(queue + 8);
@@ -165,6 +228,17 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.kind_counts = queue + 12;
     L.force_cmp = (sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     HIPCHK(agatha::launch_exotic(L, st));
+    L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;
+    L.mig_slot_dwords = 0;
+    L.timeline = nullptr;
+    L.prio_slice_bits = opt(OPT_PRIO_SLICE);
+    L.prio_duty = opt(OPT_PRIO_DUTY);
+    if (opt(OPT_TIMELINE) && workspace_bytes >= base_workspace_bytes(n_alns) + mig_workspace_bytes(n_alns)) {
+        L.timeline = timeline;
+        HIPCHK(hipMemsetAsync(timeline, 0, sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords, st));
+    }
+    L.mig_timeout_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TIMEOUT_US), 0);
+    L.mig_test_delay_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TEST_DELAY_US), 0);
     L.max_blocks_override = opt(OPT_MAX_BLOCKS);
     L.no_deal = opt(OPT_NO_DEAL) ? 1 : 0;
     // Candidates for the plain pairs: the packed-int16 kernel when the scores and the band allow it, the int32 kernel
@@ -174,6 +248,14 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.choice = choice; L.totals = totals;
     HIPCHK(agatha::plan_align(L, (int)window, opt(OPT_NO_INT16) != 0, opt(OPT_FORCE_INT16) != 0));
     g_last16 = (L.ncand > 0 && L.cand[0].kind == 1) ? ((L.cand[0].G << 8) | L.cand[0].S) : 0;
+    if (mig && L.ncand > 0 && L.cand[0].kind == 1 && L.cand[0].G < 64) {
+        const int slots = L.cand[0].capacity, dwords = agatha::align16_mig_fields(L.cand[0].S / 2) * L.cand[0].G;
+        if (slots <= agatha::kMigMaxSlots && (size_t)slots * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes) {
+            L.mig_enabled = 1; L.mig_slots = slots; L.mig_slot_dwords = dwords;
+            HIPCHK(hipMemsetAsync(mig_state, 0, sizeof(int) * ((size_t)slots + 1), st));
+            HIPCHK(agatha::launch_schedule(L, st));
+        }
+    }
     L.self_dev = rec;
     HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record, queue head reset, kernel choice; stream-ordered
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));
@@ -220,6 +302,29 @@ int agatha_amd_kernel_choice(void* stream, const void* d_workspace, uint32_t n_a
     if (choice < 0 || choice >= rec.ncand) return AGATHA_AMD_EINVAL;
     out[0] = rec.cand[choice].kind; out[1] = rec.cand[choice].G; out[2] = rec.cand[choice].S;
     return 0;
+}
+
+int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_alns, int out[3])
+{
+    if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
+    const char* ws = (const char*)d_workspace;
+    ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets);
+    hipError_t e = hipMemcpyAsync(out, ws + 16 * sizeof(unsigned int), 3 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "agatha_amd_schedule_info");
+    return 0;
+}
+
+int agatha_amd_timeline(void* stream, const void* d_workspace, uint32_t n_alns, uint32_t* out, uint32_t max_waves)
+{
+    if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
+    const char* ws = (const char*)d_workspace;
+    ws += base_workspace_bytes(n_alns) + round_up(sizeof(uint32_t) * ((size_t)n_alns + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1));
+    const uint32_t nw = std::min<uint32_t>(max_waves, agatha::kTimelineWaves);
+    hipError_t e = hipMemcpyAsync(out, ws, sizeof(uint32_t) * agatha::kTimelineDwords * nw, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "agatha_amd_timeline");
+    return (int)nw;
 }
 
 int agatha_amd_pair_kinds(void* stream, const void* d_workspace, uint32_t n_alns, uint32_t counts[3])

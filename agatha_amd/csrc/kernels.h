@@ -36,7 +36,31 @@ struct AlignLaunch {
     int max_blocks_override;       // > 0: cap of the persistent grid (tuning knob, AGATHA_AMD_MAX_BLOCKS)
     int no_deal;                   // 1 = every pair from the queue, no dealt first round (AGATHA_AMD_NO_DEAL, A/B runs)
     const AlignLaunch* self_dev;   // device copy of this record (lives in the workspace)
+    // ---- preemptive static schedule of the packed-int16 throughput shape (pairs migrate between lane groups) ----
+    int mig_enabled;               // workspace holds the areas below and the option is on
+    int mig_slots;                 // lane groups of the full persistent grid of candidate 0 (its capacity)
+    uint32_t* cum;                 // device: [n + 1] exclusive prefix sums of the pairs' step counts in sorted order
+    int* sched;                    // device: [0] 1 = static schedule in force, [1] T = steps per lane group, [2] groups used
+    int* mig_state;                // device: [mig_slots + 1] state of the pair that crosses each group boundary
+    uint32_t* mig_buf;             // device: suspended state of those pairs, mig_slot_dwords per boundary
+    int mig_slot_dwords;
+    unsigned int mig_timeout_ticks;  // 100 MHz ticks a group waits for a pair to be suspended before it takes the pair over
+    uint32_t* timeline;            // device (debug option "timeline"): per wave of the int16 kernel {start, end (100 MHz ticks), HW_ID, XCC_ID, steps, pairs}
+    int prio_slice_bits;           // > 0: the two waves of a SIMD take turns at high issue priority, in slices of 2^bits ticks of the 100 MHz clock
+    int prio_duty;                 // of every 16 slices, the wave in slot 0 of its SIMD is the favoured one in this many
+    unsigned int mig_test_delay_ticks;   // tests: odd lane groups sleep this long before they start (forces the take-over)
 };
+
+// states of a boundary (the pair whose steps are split between lane groups b - 1 and b)
+enum { MIG_FRESH = 0, MIG_RUNNING = 1, MIG_SAVED = 2, MIG_DONE = 3, MIG_STOLEN = 4 };
+// dwords of suspended state per lane of the packed-int16 kernel <G, P>: RC, H, F, XH, CORNER of the P register pairs, the 7
+// carried accumulators, the lane's (2P + 1) * 9 sixteen-bit E hand-off values (two per dword), 10 per-pair scalars
+constexpr int mig_fields(int P) { return P * 26 + 7 + ((2 * P + 1) * 9 + 1) / 2 + 10; }
+// largest `spread` (how far below an anti-diagonal maximum an in-band cell can be) the packed-int16 kernel is offered for
+constexpr int kAlign16MaxSpread = 16000;
+constexpr int kMigMaxSlots = 16384;
+constexpr int kTimelineWaves = 4096, kTimelineDwords = 8;
+constexpr size_t kMigBufBytes = (size_t)68 << 20;
 
 // window_blocks = blocks that can be live on one block-anti-diagonal.  plan_align fills L.cand / L.ncand (int16 kernel if
 // usable and not disabled, int32 throughput shape = smallest (G, S) covering the window, int32 latency shape = 64 lanes
@@ -52,6 +76,10 @@ int key_bits_for_window(int window_blocks);
 // writes L into *rec on the device (by-value kernel argument: no host-memory lifetime to care about) and zeroes *L.queue
 hipError_t launch_exotic(const AlignLaunch& L, hipStream_t st);
 hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st);
+// step counts, their prefix sums and the decision static / dynamic (after launch_sort and launch_exotic)
+hipError_t launch_schedule(const AlignLaunch& L, hipStream_t st);
+// dwords of suspended state per lane of the packed-int16 kernel <G, P>
+int align16_mig_fields(int P);
 hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint32_t* hist, uint32_t nbuckets,
                        uint32_t* order, float* totals, hipStream_t st);
 hipError_t launch_seq_ops(const uint8_t* unpacked, uint32_t* packed, const uint32_t* lens, const uint32_t* offsets,

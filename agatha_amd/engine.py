@@ -39,7 +39,7 @@ def build_library(force=False):
     src = os.path.join(_HERE, "csrc")
     if force:
         subprocess.check_call(["make", "-C", src, "-s", "clean"])
-    subprocess.check_call(["make", "-C", src, "-s", "all"])
+    subprocess.check_call(["make", "-C", src, "-s", "-j8", "all"])
     return library_path()
 
 
@@ -67,6 +67,7 @@ def load_library():
     lib.agatha_amd_workspace_bytes.restype = C.c_size_t
     lib.agatha_amd_workspace_bytes.argtypes = [C.c_uint32]
     lib.agatha_amd_pack.argtypes = [vp, vp, C.c_uint32, u32p]
+    lib.agatha_amd_pack_host.argtypes = [vp, C.c_size_t, u32p]
     lib.agatha_amd_seq_ops.argtypes = [vp, vp, u32p, u32p, u32p, vp, C.c_uint32]
     lib.agatha_amd_align.argtypes = [vp, u32p, u32p, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.POINTER(Scores), i32p, i32p, i32p, vp, C.c_size_t]
@@ -79,6 +80,8 @@ def load_library():
     lib.agatha_amd_get_debug_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
     lib.agatha_amd_pair_kinds.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.agatha_amd_kernel_choice.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
+    lib.agatha_amd_timeline.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
+    lib.agatha_amd_schedule_info.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.agatha_amd_free.argtypes = [vp]
     lib.agatha_amd_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -99,13 +102,22 @@ def load_library():
 
 EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
-    "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack",
-    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack", "agatha_amd_pack_host",
+    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
     "agatha_amd_event_destroy", "agatha_amd_event_record", "agatha_amd_event_elapsed_ms",
 ]
+
+
+def pack_host(unpacked):
+    """ASCII host batch (multiple of 8 bytes) -> packed words, on the host (agatha_amd_pack_host: AVX2)."""
+    lib = load_library()
+    u = np.ascontiguousarray(unpacked, np.uint8)
+    out = np.empty(u.size // 8, np.uint32)
+    _chk(lib, lib.agatha_amd_pack_host(u.ctypes.data, u.size, out.ctypes.data))
+    return out
 
 
 def set_debug_option(name, value):
@@ -260,6 +272,24 @@ class DeviceBatch:
         c = (C.c_int * 3)()
         _chk(lib, lib.agatha_amd_kernel_choice(st, self.d_ws.ptr, self.n, c))
         return ("int16" if c[0] else "int32", int(c[1]), int(c[2]))
+
+    def schedule_info(self, stream=None):
+        """(static schedule used, steps per lane group, lane groups used) of the last align(): see agatha_amd_schedule_info."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        c = (C.c_int * 3)()
+        _chk(lib, lib.agatha_amd_schedule_info(st, self.d_ws.ptr, self.n, c))
+        return bool(c[0]), int(c[1]), int(c[2])
+
+    def timeline(self, stream=None, max_waves=4096):
+        """Per-wave records of the int16 kernel (debug option "timeline"): array [waves, 8] of uint32, see agatha_amd_timeline."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        out = np.zeros((max_waves, 8), np.uint32)
+        nw = lib.agatha_amd_timeline(st, self.d_ws.ptr, self.n, out.ctypes.data, max_waves)
+        if nw < 0:
+            _chk(lib, nw)
+        return out[:nw]
 
     def pair_kinds(self, stream=None):
         """(plain, other letters, taken over by the int32 profile kernel) pair counts of the last align()."""

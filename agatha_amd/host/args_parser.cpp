@@ -5,7 +5,7 @@
 // Options are scanned over argv[1 .. argc-4]; the last two (three with -p) arguments are positional; argc < 4 is
 // refused; unknown single letters are ignored.  -b/-t are accepted and ignored by the HIP engine (its launch shape
 // is derived from the band); -c (extension) enables the reverse/complement op codes of the FASTA headers; -g N
-// (extension) spreads the host threads over N GPUs.
+// (extension) spreads the host threads over N GPUs; -k (extension) packs on the host (isPacked storages, ctors.cpp:65-73).
 #include "../../include/gasal_header.h"
 
 Parameters::Parameters(int argc_, char** argv_)
@@ -67,6 +67,7 @@ void Parameters::help()
     std::cerr << "         -p        print the alignment results; append kernel ms per batch to raw.log" << std::endl;
     std::cerr << "         -n INT    number of CPU threads [" << n_threads << "]" << std::endl;
     std::cerr << "         -c        apply the reverse/complement codes of the FASTA header characters (> < / +)" << std::endl;
+    std::cerr << "         -k        pack the sequences on the host and ship pre-packed batches (isPacked): half the H2D bytes" << std::endl;
     std::cerr << "         -g INT    spread the CPU threads over this many GPUs [" << n_gpus << "]" << std::endl;
     std::cerr << "         --help, -h : displays this message." << std::endl;
     std::cerr << "Single-pack multi-Parameters (e.g. -sp) is not supported." << std::endl;
@@ -96,6 +97,7 @@ void Parameters::parse()
             case 'c': isReverseComplement = true; break;
             case 'n': n_threads = next_int(c); break;
             case 'g': n_gpus = next_int(c); break;
+            case 'k': isPacked = true; break;
             case 's': slice_width = next_int(c); break;
             case 'z': z_threshold = next_int(c); break;
             case 'w': band_width = next_int(c); break;

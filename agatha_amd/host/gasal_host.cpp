@@ -170,6 +170,39 @@ uint32_t gasal_host_batch_fill(gasal_gpu_storage_t* s, uint32_t idx, const char*
     return idx;
 }
 
+// Host-side packing for isPacked storages (extension; see include/gasal_header.h).  Same page discipline as
+// gasal_host_batch_fill, in packed bytes: a sequence of `size` bases takes pad8(size) / 2 bytes.
+uint32_t gasal_host_batch_fill_packed(gasal_gpu_storage_t* s, uint32_t idx, const char* data, uint32_t size, data_source SRC)
+{
+    host_batch_t* page; uint32_t* total;
+    pick_side(s, SRC, &page, &total);
+    const uint32_t padded = pad8(size), need = padded / 2, at = idx / 2;
+    while (page->is_locked) page = page->next;
+    if (page->page_size - page->data_size < need) {
+        if (!page->next) {
+            uint32_t sz = page->page_size * 2;
+            while (sz < need) sz *= 2;
+            page->next = gasal_host_batch_new(sz, page->offset + page->data_size);
+            *total += sz;
+        } else {
+            page->next->offset = page->offset + page->data_size;
+        }
+        page->is_locked = 1;
+        page = page->next;
+    }
+    uint8_t* dst = page->data + (at - page->offset);
+    const uint32_t whole = size & ~7u;
+    CHK(agatha_amd_pack_host((const uint8_t*)data, whole, (uint32_t*)dst));
+    if (padded != whole) {
+        uint8_t tail[8];
+        memset(tail, N_CODE, 8);
+        memcpy(tail, data + whole, size - whole);
+        CHK(agatha_amd_pack_host(tail, 8, (uint32_t*)(dst + whole / 2)));
+    }
+    page->data_size += need;
+    return idx + padded;
+}
+
 // Raw append without padding (host_batch.cpp:157-225)
 uint32_t gasal_host_batch_add(gasal_gpu_storage_t* s, uint32_t idx, const char* data, uint32_t size, data_source SRC)
 {

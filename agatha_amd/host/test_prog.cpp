@@ -120,8 +120,13 @@ int main(int argc, char** argv)
                     if (st->current_n_alns > st->host_max_n_alns) gasal_host_alns_resize(st, st->host_max_n_alns * 2, args);
                     st->host_query_batch_offsets[j] = qidx;
                     st->host_target_batch_offsets[j] = tidx;
-                    qidx = gasal_host_batch_fill(st, qidx, Qs.seqs[next].c_str(), (uint32_t)Qs.seqs[next].size(), QUERY);
-                    tidx = gasal_host_batch_fill(st, tidx, Ts.seqs[next].c_str(), (uint32_t)Ts.seqs[next].size(), TARGET);
+                    if (args->isPacked) {       // -k: 4-bit words packed on the host, no pack kernel (ctors.cpp:65-73)
+                        qidx = gasal_host_batch_fill_packed(st, qidx, Qs.seqs[next].c_str(), (uint32_t)Qs.seqs[next].size(), QUERY);
+                        tidx = gasal_host_batch_fill_packed(st, tidx, Ts.seqs[next].c_str(), (uint32_t)Ts.seqs[next].size(), TARGET);
+                    } else {
+                        qidx = gasal_host_batch_fill(st, qidx, Qs.seqs[next].c_str(), (uint32_t)Qs.seqs[next].size(), QUERY);
+                        tidx = gasal_host_batch_fill(st, tidx, Ts.seqs[next].c_str(), (uint32_t)Ts.seqs[next].size(), TARGET);
+                    }
                     st->host_query_batch_lens[j] = (uint32_t)Qs.seqs[next].size();
                     st->host_target_batch_lens[j] = (uint32_t)Ts.seqs[next].size();
                 }

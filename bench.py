@@ -196,6 +196,7 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     kinds = b.pair_kinds(stream)            # how the last step's pairs were routed between the kernels
+    sched = b.schedule_info(stream)         # (static preemptive schedule used, steps per lane group, lane groups used)
     kms = [eng.elapsed_ms(e0, e1) for e0, e1 in kev] if a.steps else [float("nan")]
     kernel_ms = float(np.mean(kms))
     G, S = eng.last_config()
@@ -221,6 +222,7 @@ def main():
                        "pairs_per_gpu": a.pairs, "lanes_per_pair": Gd, "slots_per_lane": Sd, "kernel": kname,
                        "int32_fallback_kernel": f"agatha::align_kernel<{G},{S}>",
                        "pairs_plain_other_letters_int32_takeover_rank0": list(kinds),
+                       "preemptive_schedule_rank0": {"used": sched[0], "steps_per_lane_group": sched[1], "lane_groups": sched[2]},
                        "step": "pack + sort + align + D2H results" + (" + RCCL all-gather" if use_dist else "")},
             "pairs_per_s": total_pairs * a.steps / elapsed,
             "kernel_ms": kernel_ms,

@@ -55,12 +55,19 @@ int agatha_amd_set_device(int device);
 int agatha_amd_max_band(void);
 
 /* bytes of device scratch agatha_amd_align() needs for up to max_n_alns pairs (replaces the reference's
- * 0.98 GB/stream global_buffer + pinned host_buffer, ctors.cpp:89-90: this is ~4 B per pair + 64 KiB) */
+ * 0.98 GB/stream global_buffer + pinned host_buffer, ctors.cpp:89-90: this is ~5 B per pair + 64 KiB up to 4096 pairs;
+ * larger batches add ~68 MiB for the pairs that are suspended and resumed by another lane group when the batch is larger
+ * than one round of lane groups -- a caller that passes less gets the work queue instead, never an error) */
 size_t agatha_amd_workspace_bytes(uint32_t max_n_alns);
 
 /* ASCII -> packed.  Replaces the gasal_pack_kernel launch (gasal_align.cu:174-185; kernel pack_rc_seqs.h:13-53).
  * nbytes must be a multiple of 8; d_unpacked 16-byte aligned; d_packed holds nbytes/8 words. */
 int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, uint32_t* d_packed);
+
+/* The same packing on the HOST (AVX2 when the CPU has it): for callers that ship pre-packed batches -- the reference's
+ * isPacked storages (ctors.cpp:65-73, gasal_align.cu:174), which halve the H2D bytes -- and skip agatha_amd_pack().
+ * Plain host pointers, nbytes a multiple of 8, h_packed holds nbytes/8 words.  Synchronous. */
+int agatha_amd_pack_host(const uint8_t* h_unpacked, size_t nbytes, uint32_t* h_packed);
 
 /* Per-sequence reverse / complement of one side of a batch, AFTER agatha_amd_pack().  Replaces the
  * gasal_reversecomplement_kernel launch (gasal_align.cu:199-213; kernel pack_rc_seqs.h:56-212).  d_ops[k] bit 0 = reverse,
@@ -105,7 +112,10 @@ int agatha_amd_last_int16_config(void);
  *   "no_int16" (1: the packed-int16 kernel is not a candidate), "force_int16" (1: it is the only candidate when the
  *   scores and the band allow it), "force_choice" (>= 0: index of the candidate that takes the plain pairs, -1 = model),
  *   "no_deal" (1: no dealt first round), "no_migrate" (1: pairs never move between lane groups), "max_blocks"
- *   (> 0: cap of the persistent grids).
+ *   (> 0: cap of the persistent grids), "mig_timeout_us" (how long a lane group waits for a pair another group has to
+ *   suspend before it takes the pair over, default 50000), "mig_test_delay_us" (tests: odd lane groups start late),
+ *   "timeline" (1: waves record when and where they ran, agatha_amd_timeline), "prio_slice" / "prio_duty" (the
+ *   time-sliced issue priority of the two waves that share a SIMD: slice length 2^n x 10 ns, -1 = automatic, 0 = off).
  * Returns AGATHA_AMD_EINVAL for an unknown name. */
 int agatha_amd_set_debug_option(const char* name, int value);
 int agatha_amd_get_debug_option(const char* name, int* value);
@@ -117,6 +127,18 @@ int agatha_amd_get_debug_option(const char* name, int* value);
  * the batch's length histogram -- latency of the longest pair against throughput over the whole batch.)  Synchronises
  * the stream. */
 int agatha_amd_kernel_choice(void* stream, const void* d_workspace, uint32_t n_alns, int out[3]);
+
+/* Diagnostics: the preemptive schedule of the last agatha_amd_align() on this workspace.  out[0] = 1 if the packed-int16
+ * throughput kernel ran the batch on a static schedule in which pairs move between lane groups (more pairs than lane
+ * groups, up to a few rounds; the reference's subwarp rejoining, agatha_kernel.h:365-408, re-derived), out[1] = steps every
+ * lane group executes, out[2] = lane groups used.  All 0 when the work queue was used.  Synchronises the stream. */
+int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_alns, int out[3]);
+
+/* Diagnostics (debug option "timeline" = 1, workspace sized for > 4096 pairs): where and when every wave of the packed-int16
+ * kernel ran in the last agatha_amd_align() on this workspace.  8 dwords per wave (wave = 4 * workgroup + wave in
+ * workgroup): start and end in ticks of the 100 MHz real-time counter, HW_ID, XCC_ID, steps executed, pairs started, 2
+ * spare.  Returns the number of waves copied (<= max_waves) or a negative code.  Synchronises the stream. */
+int agatha_amd_timeline(void* stream, const void* d_workspace, uint32_t n_alns, uint32_t* out, uint32_t max_waves);
 
 /* Diagnostics: how the last agatha_amd_align() on this workspace routed its n_alns pairs.  counts[0] = plain pairs
  * (aligned by the packed-int16 kernel when it ran, else by the int32 profile kernel), counts[1] = pairs with letters

@@ -175,6 +175,11 @@ void gasal_host_batch_destroy(host_batch_t* res);
 host_batch_t* gasal_host_batch_getlast(host_batch_t* arg);
 void gasal_host_batch_reset(gasal_gpu_storage_t* gpu_storage);
 uint32_t gasal_host_batch_fill(gasal_gpu_storage_t* gpu_storage, uint32_t idx, const char* data, uint32_t size, data_source SRC);
+/* extension, for storages created with params->isPacked (ctors.cpp:65-73): packs `size` ASCII bases ON THE HOST (4 bit per
+ * base, padded with N to a whole word) and appends the words to the batch; idx and the return value are offsets in the
+ * UNPACKED layout (multiples of 8, what host_*_batch_offsets and gasal_aln_async's byte counts take), the page itself
+ * holds idx / 2 bytes.  The H2D copy of such a batch is half the size and no pack kernel runs (gasal_align.cu:174). */
+uint32_t gasal_host_batch_fill_packed(gasal_gpu_storage_t* gpu_storage, uint32_t idx, const char* data, uint32_t size, data_source SRC);
 uint32_t gasal_host_batch_add(gasal_gpu_storage_t* gpu_storage, uint32_t idx, const char* data, uint32_t size, data_source SRC);
 uint32_t gasal_host_batch_addbase(gasal_gpu_storage_t* gpu_storage, uint32_t idx, const char base, data_source SRC);
 void gasal_host_batch_print(host_batch_t* res);

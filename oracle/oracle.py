@@ -26,7 +26,7 @@ def make_params(m=2, x=4, q=4, r=2, s=3, z=400, w=751):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("agatha_oracle.c", "agatha_lanes_model.c", "ksw_style_avx2.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("agatha_oracle.c", "agatha_lanes_model.c", "ksw_style_avx2.c", "seq_ops_ref.c", "Makefile")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     return _LIB
@@ -54,6 +54,9 @@ def lib():
         _lib.ksw_style_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p,
                                                             C.c_void_p, C.POINTER(C.c_int)]
         _lib.ksw_style_batch.restype = None
+        for f in (_lib.agatha_ref_seq_ops_as_written, _lib.agatha_seq_ops_product_semantics):
+            f.argtypes = [C.c_void_p] * 4 + [C.c_int]
+            f.restype = None
     return _lib
 
 
@@ -61,6 +64,18 @@ from agatha_amd.workload import make_batch  # noqa: E402  (wire-format helper li
 
 
 MODEL_SLICES, MODEL_STEPS, MODEL_EXACTBAND = 0, 1, 2
+
+
+def seq_ops(packed, lens, offsets, ops, as_written):
+    """Per-sequence reverse / complement of one side of a packed batch (oracle/seq_ops_ref.c): as_written=True restates the
+    reference's gasal_reversecomplement_kernel (pack_rc_seqs.h:56-212) exactly as its text behaves, False the semantics the
+    product implements (reverse exactly len bases, padding stays behind).  Returns a new array."""
+    out = np.ascontiguousarray(packed, np.uint32).copy()
+    lens, offsets = np.ascontiguousarray(lens, np.uint32), np.ascontiguousarray(offsets, np.uint32)
+    ops = np.ascontiguousarray(ops, np.uint8)
+    f = lib().agatha_ref_seq_ops_as_written if as_written else lib().agatha_seq_ops_product_semantics
+    f(out.ctypes.data, lens.ctypes.data, offsets.ctypes.data, ops.ctypes.data, len(lens))
+    return out
 
 
 def align_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, wide=False, model=MODEL_SLICES, threads=1):

@@ -43,7 +43,9 @@ def test_library_reports_limits_without_a_gpu():
     import agatha_amd
     lib = agatha_amd.load_library()
     assert lib.agatha_amd_max_band() >= 1500          # BASELINE config 3 needs band 1500
-    assert lib.agatha_amd_workspace_bytes(8192) < (1 << 20)
+    assert lib.agatha_amd_workspace_bytes(4096) < (1 << 20)
+    # batches that can exceed one round of lane groups also carry the areas of the preemptive schedule (suspended pairs)
+    assert lib.agatha_amd_workspace_bytes(8192) < (80 << 20)          # the reference: 0.98 GB per stream (ctors.cpp:89)
     assert lib.agatha_amd_strerror(-2).decode().startswith("band")
 
 
@@ -124,3 +126,16 @@ def test_reference_client_builds_against_this_boundary(tmp_path):
     r = subprocess.run([str(exe), "a.fa", "b.fa"], capture_output=True, text=True)
     assert r.returncode == 1 and "Not enough" in r.stderr
     edited.unlink()          # no reference text stays behind, not even under pytest's tmp dir
+
+
+def test_host_packer_matches_the_pack_layout():
+    """agatha_amd_pack_host (AVX2): the reference's 4-bit layout (pack_rc_seqs.h:21-33), checked against the oracle's
+    restatement for every tail length of the vector loop, any letter, both cases."""
+    import numpy as np
+    import agatha_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(1)
+    letters = np.frombuffer(b"ACGTNacgtnRYKM", np.uint8)
+    for n in [8 * k for k in range(1, 20)] + [4096, 100008]:
+        a = letters[rng.integers(0, letters.size, n)].copy()
+        assert (agatha_amd.pack_host(a) == O.pack(a)).all(), n

@@ -150,3 +150,27 @@ def test_reference_client_and_manual_behave_alike(tmp_path):
         else:
             for o in outs.values():
                 match_batches(parse(o), [exp[k:k + align_num] for k in range(0, 600, align_num)])
+
+
+def test_cli_prepacked_batches_through_the_gasal_api(tmp_path):
+    """f3: `manual -k` creates its storages with isPacked (ctors.cpp:65-73), packs every sequence on the host
+    (gasal_host_batch_fill_packed -> agatha_amd_pack_host) and gasal_aln_async skips the pack kernel (gasal_align.cu:174):
+    half the H2D bytes, identical score lines.  Several batches, pages that grow, lengths of every residue mod 8."""
+    qs, ts = synth.cfg_c4(n=400, seed=12, lo=50, hi=6000)
+    f1, f2 = tmp_path / "ref.fasta", tmp_path / "query.fasta"
+    write_fasta(f1, qs, header=">")
+    write_fasta(f2, ts, header=">")
+    outs = []
+    for extra in ([], ["-k"]):
+        raw = tmp_path / ("raw%d.log" % len(extra))
+        r = subprocess.run([MANUAL, "-p"] + extra + ["-m", "1", "-x", "4", "-q", "6", "-r", "2", "-z", "400", "-w", "751", "-a", "150",
+                            str(f1), str(f2), str(raw)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert len(open(raw).read().split()) == 3
+        outs.append(parse(r.stdout))
+    exp = np.stack(O.align_pairs(qs, ts, O.make_params(m=1, x=4, q=6, r=2, s=3, z=400, w=751), wide=True, threads=4), axis=1)
+    for o in outs:
+        match_batches(o, [exp[k:k + 150] for k in range(0, 400, 150)])
+    # ops + pre-packed together are refused, as documented
+    r = subprocess.run([MANUAL, "-p", "-k", "-c", "-w", "100", str(f1), str(f2), str(tmp_path / "r.log")], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "isPacked" in r.stderr

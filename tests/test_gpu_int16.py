@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+import agatha_amd
 from oracle import oracle as O
 from agatha_amd import workload as WL
 
@@ -304,3 +305,88 @@ def test_pairs_longer_than_the_16_bit_block_indices(eng):
         assert b.kernel_choice()[0] == "int16" and b.pair_kinds() == (6, 0, 1)
     finally:
         b.free()
+
+
+def _mig_batch(n, seed, lo, hi, broken=0.0):
+    """n pairs for a narrow band; `broken`: share of pairs whose read turns into an unrelated sequence somewhere (z-drop)."""
+    rng = np.random.default_rng(seed)
+    qs, ts = [], []
+    for k in range(n):
+        ref = WL.random_seq(rng, int(rng.integers(lo, hi)))
+        rd = WL.mutate(rng, ref, 0.03, 0.03, 0.04)
+        if rng.random() < broken:
+            bp = int(rng.integers(0, max(1, rd.size)))
+            rd = np.concatenate([rd[:bp], WL.random_seq(rng, ref.size - min(bp, ref.size) + 8)])
+        if rd.size == 0:
+            rd = WL.random_seq(rng, 1)
+        ref, rd = ref.copy(), rd.copy()
+        if k % 97 == 5:
+            ref[rng.integers(0, ref.size)] = ord("N")          # N in the query: the int32 kernel's pair, skipped here
+        qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    return qs, ts
+
+
+def _run_scheduled(eng, qs, ts, p):
+    qb, qo, ql = WL.make_batch(qs)
+    tb, to, tl = WL.make_batch(ts)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=8)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p)); b.download()
+        eng.synchronize()
+        got = [b.res_host[k].copy() for k in range(3)]
+        return got, exp, b.schedule_info(), b.kernel_choice()
+    finally:
+        b.free()
+
+
+@pytest.mark.parametrize("n,w,lo,hi", [(8200, 24, 300, 1200), (9500, 24, 40, 900), (12288, 24, 200, 700), (15000, 40, 100, 800),
+                                       (9000, 300, 500, 1500), (20000, 24, 100, 400)])
+def test_pairs_migrate_between_lane_groups(eng, n, w, lo, hi):
+    """More pairs than lane groups (8192 for these bands): the int16 kernel runs a static preemptive schedule -- every lane
+    group executes T = max(longest pair, total steps / groups) steps, and the pair that crosses a group boundary is
+    suspended by one group and resumed by its neighbour (the reference's subwarp rejoining, agatha_kernel.h:365-408,
+    re-derived: pairs in flight move to lane groups that would idle).  Bit-exact against the oracle, and identical to the
+    run with the work queue."""
+    qs, ts = _mig_batch(n, n + w, lo, hi)
+    p = dict(BASE, w=w)
+    agatha_amd.set_debug_option("force_choice", 0)             # the int16 throughput shape
+    try:
+        got, exp, info, choice = _run_scheduled(eng, qs, ts, p)
+        assert choice[0] == "int16" and choice[1] == 16
+        assert info[0] and info[2] <= 8192 and info[1] >= 1, info
+        assert _same(got, exp)
+        with agatha_amd.debug_options(no_migrate=1):
+            got2, _, info2, _ = _run_scheduled(eng, qs, ts, p)
+        assert not info2[0] and _same(got2, exp)
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
+
+
+def test_migration_with_zdrop_in_the_first_part(eng):
+    """Pairs that end (z-drop) inside the part their first lane group runs: the second group must find nothing to resume."""
+    qs, ts = _mig_batch(10000, 5, 200, 1500, broken=0.5)
+    p = dict(BASE, w=24, z=60)
+    agatha_amd.set_debug_option("force_choice", 0)
+    try:
+        got, exp, info, _ = _run_scheduled(eng, qs, ts, p)
+        assert info[0]
+        assert _same(got, exp)
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
+
+
+def test_migration_take_over_when_the_first_part_never_comes(eng):
+    """A lane group that waits too long for the pair its neighbour has to suspend takes the pair over and runs it from its
+    first step (deadlock-freedom when the neighbour's workgroup is not resident).  Forced here: odd lane groups start 20 ms
+    late, the wait is cut to 1 ms."""
+    qs, ts = _mig_batch(9000, 6, 200, 900)
+    p = dict(BASE, w=24)
+    agatha_amd.set_debug_option("force_choice", 0)
+    try:
+        with agatha_amd.debug_options(mig_timeout_us=1000, mig_test_delay_us=20000):
+            got, exp, info, _ = _run_scheduled(eng, qs, ts, p)
+        assert info[0]
+        assert _same(got, exp)
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)

@@ -1,10 +1,12 @@
 """GPU parity: the HIP path (through the C-ABI of libagatha_amd.so) against the oracle and the golden vectors.
 Everything here needs a real MI355X: run with `pytest -m gpu`."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import oracle as O, synth
-from helpers import load_kats, load_ref_vectors
+from helpers import load_kats, load_ref_vectors, GOLDEN as GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
 
@@ -203,3 +205,39 @@ def test_prepacked_input(eng):
             assert np.array_equal(b.res_host[k], exp[k])
     finally:
         b.free()
+
+
+def test_seq_ops_kernel_against_the_reference_as_written(eng):
+    """f2: agatha::seq_ops_kernel against the fixture produced by the restatement of the reference's
+    gasal_reversecomplement_kernel (pack_rc_seqs.h:56-212, oracle/seq_ops_ref.c).  (a) For len % 8 == 0 (and for ops that
+    do not reverse) the kernel's packed words EQUAL the reference's; (b) for len % 8 != 0 with a reversal they differ in
+    exactly the documented way: the reference, as written, rotates the padding Ns to the front, the kernel reverses the
+    len real bases and keeps the padding behind them (= oracle's product semantics)."""
+    import json
+    d = json.load(open(os.path.join(GOLDEN_DIR, "seq_ops_as_written.json")))
+    seqs = [s.encode() for s in d["seqs"]]
+    ops = np.asarray(d["ops"], np.uint8)
+    ref = np.asarray(d["packed_after"], np.uint32)
+    buf, offs, lens = O.make_batch(seqs)
+    b = eng.batch(buf, buf, offs, offs, lens, lens)
+    try:
+        b.upload(); b.pack(); b.seq_ops(ops, None)
+        got, untouched = b.packed_host()
+    finally:
+        b.free()
+    assert (untouched == O.pack(buf)).all()
+    prod = O.seq_ops(O.pack(buf), lens, offs, ops, as_written=False)
+    assert (got == prod).all()
+    n_equal = n_diff = 0
+    for s, o, off in zip(seqs, ops, offs):
+        w0, w1 = int(off) // 8, (int(off) + len(s) + 7) // 8
+        if len(s) % 8 == 0 or not (o & 1):
+            assert (got[w0:w1] == ref[w0:w1]).all(), (len(s), int(o))              # (a)
+            n_equal += 1
+        else:
+            assert (got[w0:w1] != ref[w0:w1]).any(), (len(s), int(o))              # (b)
+            pad = (-len(s)) % 8
+            nib = lambda words: [(int(w) >> (28 - 4 * k)) & 15 for w in words for k in range(8)]
+            assert nib(ref[w0:w1])[:pad] == [14] * pad and nib(got[w0:w1])[len(s):] == [14] * pad
+            n_diff += 1
+    assert n_equal > 40 and n_diff > 40

@@ -1,4 +1,6 @@
 """CPU-only: the oracle against the reference's known answers, and its two schedules against each other."""
+import os
+
 import numpy as np
 import pytest
 
@@ -172,3 +174,43 @@ def test_int16_kernel_model_equals_oracle(seed):
             assert st[0] >= -32768 and st[1] <= 32767          # no int16 wrap anywhere
             assert st[2] < -22000 and st[3] >= -22000          # out-of-band cells below, in-band cells above L16_GLO
     assert fell_back < 10 * 16 // 2
+
+
+def _seq_ops_fixture():
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seq_ops_as_written.json")))
+    seqs = [s.encode() for s in d["seqs"]]
+    return seqs, np.asarray(d["ops"], np.uint8), np.asarray(d["packed_after"], np.uint32)
+
+
+def _py_transform(seq, op, pad_first):
+    """Reverse / complement of the string.  pad_first: reverse the PADDED sequence, as the reference's kernel does as
+    written (the padding Ns end up in front)."""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    s = seq + b"N" * ((-len(seq)) % 8) if pad_first else seq
+    s = s[::-1] if op & 1 else s
+    return s.translate(comp) if op & 2 else s
+
+
+def test_seq_ops_reference_as_written_and_product_semantics():
+    """f2 (reverse / complement op path): oracle/seq_ops_ref.c restates the reference's gasal_reversecomplement_kernel
+    (pack_rc_seqs.h:56-212) as written and the semantics the product implements.  Pinned here: (1) the restatement
+    reproduces the committed fixture; (2) as written, the reference reverses the PADDED sequence (its count of padding
+    bases compares a nibble with 0x4E and is always 0, :113-116), so padding Ns rotate to the front; (3) the product
+    semantics reverse exactly len bases; (4) the two agree exactly when len % 8 == 0 or the op does not reverse."""
+    seqs, ops, after = _seq_ops_fixture()
+    buf, offs, lens = O.make_batch(seqs)
+    packed = O.pack(buf)
+    ref = O.seq_ops(packed, lens, offs, ops, as_written=True)
+    assert (ref == after).all()                                                                    # (1)
+    padded = [_py_transform(s, int(o), True) for s, o in zip(seqs, ops)]
+    assert (ref == O.pack(O.make_batch(padded)[0])).all()                                          # (2)
+    prod = O.seq_ops(packed, lens, offs, ops, as_written=False)
+    assert (prod == O.pack(O.make_batch([_py_transform(s, int(o), False) for s, o in zip(seqs, ops)])[0])).all()   # (3)
+    n_diff = 0
+    for s, o, off in zip(seqs, ops, offs):                                                         # (4)
+        w0, w1 = int(off) // 8, (int(off) + len(s) + 7) // 8
+        same = (ref[w0:w1] == prod[w0:w1]).all()
+        assert same == (len(s) % 8 == 0 or not (o & 1)), (len(s), int(o))
+        n_diff += not same
+    assert n_diff > 20

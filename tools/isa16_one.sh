@@ -4,18 +4,8 @@
 G=${1:-16}; P=${2:-3}; T0=${3:--1}
 cd "$(dirname "$0")/../agatha_amd/csrc"
 mkdir -p /tmp/isa16
-python3 - "$G" "$P" "$T0" <<'PY'
-import sys
-G, P, T0 = sys.argv[1:4]
-s = open('align16_kernel.hip').read()
-a = s.index('static const Cfg16 kCfgs16[] = {'); b = s.index('};', a)
-one = 'launch_align16_t<%s, %s, %s>' % (G, P, T0)
-s = s[:a] + 'static const Cfg16 kCfgs16[] = {\n  {%s, %s, {%s}},\n' % (G, P, ', '.join([one] * 8)) + s[b:]
-open('/tmp/isa16/one.hip', 'w').write(s)
-PY
-cp kernels.h device_common.h /tmp/isa16/
 FLAGS=$(grep '^CXXFLAGS' Makefile | sed 's/CXXFLAGS *= *//; s/\$(ARCH)/gfx950/')
-hipcc $FLAGS -S --cuda-device-only -o /tmp/isa16/one.s /tmp/isa16/one.hip -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|VGPRs:|SGPRs:|Spill|Occupancy|Scratch"
+hipcc $FLAGS -DAGATHA16_NT0=$((-T0)) -DAGATHA16_ONLY_G=$G -DAGATHA16_ONLY_P=$P -S --cuda-device-only -o /tmp/isa16/one.s align16_inst.hip -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|VGPRs:|SGPRs:|Spill|Occupancy|Scratch"
 python3 - <<'PY'
 import re, collections
 out, skip = [], False
