@@ -723,6 +723,7 @@ schedule_kernel(AlignLaunch L, int GS)
 {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t pmaxs[1024];
+    __shared__ uint32_t nzs[1024];
     const int n = L.n, m = L.mig_slots, t = threadIdx.x;
     if (!L.mig_enabled || m <= 0 || n <= m || (long long)n > 8ll * m) { if (t == 0) L.sched[0] = 0; return; }
     const int W = (L.p.band_width + 7) >> 3, sw = L.p.slice_width;
@@ -737,17 +738,24 @@ schedule_kernel(AlignLaunch L, int GS)
         const int total = pql + prl - 1;
         return (uint32_t)(((total + sw - 1) / sw) * sw + 2);  // dry step + whole slices + the final check step
     };
-    uint32_t sum = 0, mx = 0;
-    for (int j = j0; j < j1; j++) { const uint32_t p = steps_of(j); sum += p; mx = max(mx, p); }
-    part[t] = sum; pmaxs[t] = mx;
+    uint32_t sum = 0, mx = 0, nz = 0;
+    for (int j = j0; j < j1; j++) { const uint32_t p = steps_of(j); sum += p; mx = max(mx, p); nz += p > 1u; }
+    part[t] = sum; pmaxs[t] = mx; nzs[t] = nz;
     __syncthreads();
     if (t == 0) {
-        uint32_t acc = 0, pm = 0;
-        for (int k = 0; k < 1024; k++) { const uint32_t v = part[k]; part[k] = acc; acc += v; pm = max(pm, pmaxs[k]); }
-        const long long P = acc;
+        unsigned long long acc = 0;          // (the 32-bit prefix sums are only used when the total stays below 2^30)
+        uint32_t pm = 0, npairs = 0;
+        for (int k = 0; k < 1024; k++) { const uint32_t v = part[k]; part[k] = (uint32_t)acc; acc += v; pm = max(pm, pmaxs[k]); npairs += nzs[k]; }
+        const long long P = (long long)acc;
         long long T = (P + m - 1) / m; if (T < (long long)pm) T = pm; if (T < 1) T = 1;
-        L.cum[n] = acc;
-        const bool use = pm > 0 && P <= 4ll * m * (long long)pm && P < (1ll << 30);
+        L.cum[n] = (uint32_t)acc;
+        // When is the static schedule the better one (measured): always up to ~2 rounds of pairs (the work queue
+        // then ends in a long tail on a few waves); up to 8 rounds when the pairs are long against the band -- the four lane
+        // groups of a wave then start their pairs at different times, and every pair start is ~W steps on slower code paths,
+        // which short pairs (a bundled-dataset-like batch: 750 steps each) pay for more than they gain; beyond 8 rounds the
+        // queue balances by itself and also follows pairs that z-drop early.
+        const long long pavg = npairs ? P / (long long)npairs : 0;
+        const bool use = pm > 0 && P < (1ll << 30) && (10ll * n <= 22ll * m || pavg >= 12ll * (W + 1));
         L.sched[0] = use ? 1 : 0; L.sched[1] = (int)T; L.sched[2] = (int)((P + T - 1) / T);
     }
     __syncthreads();

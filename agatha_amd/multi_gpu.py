@@ -6,8 +6,9 @@
 Same scoring flags and output lines as the single-GPU CLI (`agatha_amd/manual -p`, reference test_prog.cpp:361-369),
 always in input order.  The reference is single-GPU (its gasal_set_device hook is never called, test_prog.cpp:31):
 this front end is the "shard the batch over the 8 GPUs, gather 12 bytes per pair" step of the design.
-Every rank parses both files (they are read once, sequentially), takes its LPT share of the pairs by nominal cells,
-runs the ordinary single-GPU hot path on it and joins one all-gather.
+Every rank INDEXES both files (a vectorised scan for line starts: record offsets, op codes and lengths, no sequence is
+decoded), takes its LPT share of the pairs by nominal cells, reads only the byte ranges of its own records, runs the
+ordinary single-GPU hot path on them and joins one all-gather.
 """
 import argparse
 import os
@@ -44,6 +45,56 @@ def read_fasta(path):
     return seqs, np.asarray(ops, np.uint8)
 
 
+def fasta_index(path, chunk=1 << 26):
+    """Record table of a FASTA file without decoding it: (ops uint8[n], start int64[n], end int64[n], length int64[n]) --
+    op code of the header character, byte range of the record's sequence lines, number of bases.  Vectorised: newline
+    positions are collected chunk by chunk, the first byte of every line tells header lines from sequence lines."""
+    size = os.path.getsize(path)
+    if size == 0:
+        return np.zeros(0, np.uint8), np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64)
+    if True:
+        buf = np.memmap(path, dtype=np.uint8, mode="r")
+        nls, ncr = [], []
+        for lo in range(0, size, chunk):
+            part = buf[lo:lo + chunk]
+            nls.append(np.flatnonzero(part == 10).astype(np.int64) + lo)
+            cr = np.flatnonzero(part == 13).astype(np.int64) + lo
+            if cr.size:
+                ncr.append(cr)
+        nl = np.concatenate(nls)
+        starts = np.concatenate([[0], nl + 1]).astype(np.int64)
+        starts = starts[starts < size]                                   # line starts
+        ends = np.concatenate([nl, [size]])[:starts.size]                # position of each line's newline (or EOF)
+        first = buf[starts]
+        nonempty = ends > starts
+        hdr = np.isin(first, np.frombuffer(_OPS, np.uint8)) & nonempty
+        hidx = np.flatnonzero(hdr)
+        if hidx.size == 0 or (nonempty[:hidx[0]].any()):
+            raise SystemExit("Batch1 and target_batch files should be fasta having same number of sequences")
+        ops = np.searchsorted(np.sort(np.frombuffer(_OPS, np.uint8)), first[hidx])
+        ops = np.argsort(np.frombuffer(_OPS, np.uint8))[ops].astype(np.uint8)      # index into "></+"
+        rstart = np.minimum(ends[hidx] + 1, size)                        # first byte after the header line
+        rend = np.concatenate([starts[hidx[1:]], [size]])                # start of the next header (or EOF)
+        # bases = bytes of the region minus its newlines (and carriage returns)
+        nl_before = np.searchsorted(nl, rend) - np.searchsorted(nl, rstart)
+        length = rend - rstart - nl_before
+        if ncr:
+            crs = np.concatenate(ncr)
+            length -= np.searchsorted(crs, rend) - np.searchsorted(crs, rstart)
+        del buf, first
+    return ops, rstart, rend, length.astype(np.int64)
+
+
+def read_records(path, start, end, ids):
+    """The sequences of the records `ids` only (byte ranges from fasta_index), newlines stripped."""
+    out = []
+    with open(path, "rb") as f:
+        for i in ids:
+            f.seek(int(start[i]))
+            out.append(f.read(int(end[i] - start[i])).replace(b"\n", b"").replace(b"\r", b""))
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(add_help=True)
     for flag, dest, default in (("-m", "m", 2), ("-x", "x", 4), ("-q", "q", 4), ("-r", "r", 2), ("-s", "s", 3),
@@ -73,13 +124,11 @@ def main(argv=None):
         else:
             dist.init_process_group(a.backend)
 
-    qs, qops = read_fasta(a.query_batch_fasta)
-    ts, tops = read_fasta(a.target_batch_fasta)
-    if len(qs) != len(ts) or not qs:
+    qops, qstart, qend, ql = fasta_index(a.query_batch_fasta)
+    tops, tstart, tend, tl = fasta_index(a.target_batch_fasta)
+    if len(ql) != len(tl) or len(ql) == 0:
         raise SystemExit("Batch1 and target_batch files should be fasta having same number of sequences")
-    n = len(qs)
-    ql = np.fromiter((len(s) for s in qs), np.int64, n)
-    tl = np.fromiter((len(s) for s in ts), np.int64, n)
+    n = len(ql)
     mine = shard.lpt_partition(shard.nominal_cells(ql, tl, a.w), world)[rank]
 
     eng = Engine(local_rank)
@@ -87,8 +136,8 @@ def main(argv=None):
     local = [np.zeros(len(mine), np.int32) for _ in range(3)]
     for lo in range(0, len(mine), a.a):                 # batches of -a pairs, as the reference CLI cuts them
         idx = mine[lo:lo + a.a]
-        qb, qo, qlen = workload.make_batch([qs[i] for i in idx])
-        tb, to, tlen = workload.make_batch([ts[i] for i in idx])
+        qb, qo, qlen = workload.make_batch(read_records(a.query_batch_fasta, qstart, qend, idx))     # this rank's byte ranges only
+        tb, to, tlen = workload.make_batch(read_records(a.target_batch_fasta, tstart, tend, idx))
         res = eng.align_host_batch(qb, tb, qo, to, qlen, tlen, scores,
                                    qops=qops[idx] if a.ops else None, tops=tops[idx] if a.ops else None)
         for k in range(3):

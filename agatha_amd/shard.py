@@ -8,52 +8,40 @@ import numpy as np
 
 
 def nominal_cells(qlen, tlen, w):
-    """In-band DP cells per pair, closed form of sum_i (min(R-1, i+w) - max(0, i-w) + 1)."""
+    """In-band DP cells per pair, sum_i clip(min(R-1, i+w) - max(0, i-w) + 1, 0) over the rows i < Q, in
+    closed form and vectorised over the pairs: the summand is piecewise linear in i with breakpoints at w + 1, R - w and
+    R + w, so each pair is at most four trapezoids."""
     Q = np.asarray(qlen, np.int64)
     R = np.asarray(tlen, np.int64)
-    w = int(w)
-    out = np.zeros(Q.shape, np.int64)
-    for k in range(Q.size):          # vectorised per pair over rows would cost O(sum Q); use the piecewise closed form
-        q, r = int(Q[k]), int(R[k])
-        if q <= 0 or r <= 0:
-            continue
-        # rows 0..q-1; hi(i) = min(r-1, i+w), lo(i) = max(0, i-w); count = hi - lo + 1 when >= 1
-        i = np.arange(q, dtype=np.int64) if q < 4096 else None
-        if i is not None:
-            c = np.minimum(r - 1, i + w) - np.maximum(0, i - w) + 1
-            out[k] = int(np.clip(c, 0, None).sum())
-        else:
-            out[k] = _cells_closed(q, r, w)
-    return out
+    w = np.int64(w)
 
+    def f(i):           # the summand at row i (arrays)
+        return np.clip(np.minimum(R - 1, i + w) - np.maximum(0, i - w) + 1, 0, None)
 
-def _cells_closed(q, r, w):
-    # sum over rows of clip(min(r-1, i+w) - max(0, i-w) + 1, 0): piecewise linear, evaluate by segments
-    pts = sorted(set([0, q, max(0, min(q, w)), max(0, min(q, r - 1 - w)), max(0, min(q, r + w))]))
-    total = 0
-    for a, b in zip(pts[:-1], pts[1:]):
-        if b <= a:
-            continue
-        # the summand is linear on [a, b-1]: evaluate at both ends
-        def f(i):
-            return max(0, min(r - 1, i + w) - max(0, i - w) + 1)
-        fa, fb = f(a), f(b - 1)
-        total += (fa + fb) * (b - a) // 2
-    return total
+    zero = np.zeros_like(Q)
+    # rows are cut at the sorted, clipped breakpoints; on every piece [a, b) the summand is linear (or identically 0)
+    cuts = np.sort(np.stack([zero, np.clip(w + 1, 0, Q), np.clip(R - w, 0, Q), np.clip(R + w, 0, Q), np.clip(Q, 0, None)]), axis=0)
+    total = np.zeros_like(Q)
+    for k in range(4):
+        a, b = cuts[k], cuts[k + 1]
+        n = np.clip(b - a, 0, None)
+        total += (f(a) + f(np.maximum(b - 1, a))) * n // 2          # trapezoid: (first + last) * count / 2 (always even)
+    return np.where((Q > 0) & (R > 0), total, 0)
 
 
 def lpt_partition(cost, world):
-    """Longest-processing-time-first: deal pairs, most expensive first, to the least loaded rank.
-    Returns a list of index arrays (original pair ids per rank)."""
+    """Longest-processing-time-first: deal pairs, most expensive first, to the least loaded rank (a heap: O(n log G)).
+    Returns a list of index arrays (original pair ids per rank, ascending)."""
+    import heapq
     cost = np.asarray(cost, np.int64)
     order = np.argsort(-cost, kind="stable")
-    loads = np.zeros(world, np.int64)
-    parts = [[] for _ in range(world)]
-    for idx in order:
-        g = int(np.argmin(loads))
-        parts[g].append(int(idx))
-        loads[g] += int(cost[idx])
-    return [np.asarray(sorted(p), np.int64) for p in parts]
+    heap = [(0, g) for g in range(world)]
+    owner = np.empty(cost.size, np.int32)
+    for idx, c in zip(order.tolist(), cost[order].tolist()):
+        load, g = heap[0]
+        owner[idx] = g
+        heapq.heapreplace(heap, (load + c, g))
+    return [np.flatnonzero(owner == g).astype(np.int64) for g in range(world)]
 
 
 def take_pairs(qbuf, tbuf, qoff, toff, qlen, tlen, idx):
@@ -94,4 +82,29 @@ def gather_results(local, idx, n_total, dist=None, device=None):
         a = allr[g].cpu().numpy()
         k = int(counts[g].item())
         out[:, a[3, :k]] = a[:3, :k]
+    return out
+
+
+def gather_results_tensor(local, idx, n_total, dist, torch):
+    """The strong-scaling exchange on tensors (GPU tensors over RCCL in bench.py, CPU tensors over gloo in the tests):
+    `local` is this rank's (3, n_local) int32 result tensor, `idx` the (n_local,) int64 original pair ids.  One
+    all-gather of 4 x nmax int32 per rank (results + ids, padded to the largest shard), then a scatter into input order.
+    Returns the (3, n_total) tensor on every rank."""
+    world = dist.get_world_size()
+    n_local = int(local.shape[1])
+    counts = torch.zeros(world, dtype=torch.int64, device=local.device)
+    counts[dist.get_rank()] = n_local
+    dist.all_reduce(counts)
+    nmax = int(counts.max().item())
+    pad = torch.full((4, nmax), -1, dtype=torch.int32, device=local.device)
+    pad[:3, :n_local] = local
+    pad[3, :n_local] = idx.to(torch.int32)
+    flat = torch.empty((world * 4, nmax), dtype=torch.int32, device=local.device)      # concatenation along dim 0 (NCCL and gloo)
+    dist.all_gather_into_tensor(flat, pad)
+    allr = flat.view(world, 4, nmax)
+    ids = allr[:, 3, :].reshape(-1).to(torch.int64)
+    vals = allr[:, :3, :].permute(1, 0, 2).reshape(3, -1)
+    keep = ids >= 0
+    out = torch.zeros((3, n_total), dtype=torch.int32, device=local.device)
+    out[:, ids[keep]] = vals[:, keep]
     return out

@@ -7,7 +7,9 @@ A "step" is one pass of the hot path over one batch that is already resident in 
 (the state right after the H2D copy in the reference's gasal_aln_async): pack -> length sort -> align ->
 D2H of the three result arrays (+ for N > 1 an RCCL all-gather of the results, the only collective).
 Workload = BASELINE.json configs[1]: 10 k synthetic ONT-like pairs, ~10 kb, band 751, z-drop 400, m2 x4 q4 r2,
-per GPU (weak scaling: every rank aligns its own 10 k pairs).  Prints ONE JSON line on rank 0.
+per GPU (weak scaling: every rank aligns its own 10 k pairs; `--scaling strong`: ONE batch, LPT-sharded over the ranks by
+nominal cells, results gathered into input order with one all-gather and verified on rank 0 against a single-GPU run).
+`--config C0..C4` times the other BASELINE workload shapes with the same fields.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -27,6 +29,17 @@ VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # algorithmic VALU lane-ops of one DP cell incl. the anti-diagonal maximum: 11 int32 ops per cell in the
 # int32 kernel; 10 packed ops per TWO cells in the packed-int16 kernel (2 score adds, 4 max, 1 sub, 2 key mads, 1 max3)
 OPS_PER_CELL = {"int32": 11.0, "int16": 5.0}
+
+
+# BASELINE.json's workload shapes; "pairs" is the size that fits one GPU comfortably (C2 is 100 k pairs on 8
+# GPUs = 12.5 k per GPU; C4's 20 k pairs are cut to 6 k so that the default run stays within minutes)
+CONFIGS = {
+    "C0": dict(gen="cfg_c0", pairs=20000, w=751, z=400, scoring=dict(m=2, x=4, q=4, r=2), text="bundled-dataset stand-in: ~3 kb pairs (N(3000,1000) clipped 200-8000), sub 4% ins 3% del 3%"),
+    "C1": dict(gen="cfg_c1", pairs=10000, w=751, z=400, scoring=dict(m=2, x=4, q=4, r=2), text="synthetic ONT-like pairs, ~10 kb (8-12 kb), sub 3% ins 3% del 4%"),
+    "C2": dict(gen="cfg_c2", pairs=12500, w=500, z=400, scoring=dict(m=2, x=4, q=4, r=2), text="PacBio-HiFi-like pairs, 15-20 kb, sub 0.2% ins 0.4% del 0.4%"),
+    "C3": dict(gen="cfg_c3", pairs=256, w=1500, z=400, scoring=dict(m=2, x=4, q=4, r=2), text="ultra-long ONT-like pairs, ~100 kb (N(100000,10000))"),
+    "C4": dict(gen="cfg_c4", pairs=6000, w=751, z=400, scoring=dict(m=2, x=4, q=4, r=2), text="mixed lengths 1-100 kb (log-uniform), 30% broken / high-error pairs (heavy z-drop)"),
+}
 
 
 def algorithmic_bytes(qlen, tlen):
@@ -76,7 +89,7 @@ def cpu_baseline(qb, tb, qo, to, ql, tl, scoring, w, budget_s=12.0, gpu_res=None
         dt += d2
         reps += 1
     cells = O.nominal_cells_np(ql[:k], tl[:k], w) * reps
-    ks = int(min(k, max(2 * cores, k // 16)))          # the scalar port is ~20x slower: a 16th of the sample
+    ks = int(min(k, max(2 * cores, 2000, k // 16)))    # the scalar restatement of the reference kernel: >= 2000 pairs (~4 s on 16 cores)
     r_scal, dts = timed(scal, ks)
     same = int(sum(int((r_simd[0][i] == r_scal[0][i]) and (r_simd[1][i] == r_scal[1][i]) and (r_simd[2][i] == r_scal[2][i]))
                    for i in range(ks)))
@@ -100,9 +113,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=10000, help="pairs per GPU (BASELINE config: 10000)")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs (per GPU when weak scaling); default: the config's own size")
+    ap.add_argument("--config", default="C1", choices=sorted(CONFIGS), help="workload shape of BASELINE.json (default C1 = configs[1], the headline)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank aligns its own batch; strong: ONE batch, LPT-sharded over the ranks, results gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    if a.pairs <= 0:
+        a.pairs = cfg["pairs"]
 
     # RCCL / HIP print banners to fd 1 on some boxes (NCCL_DEBUG=VERSION): keep stdout clean for the ONE JSON line
     sys.stdout.flush()
@@ -129,22 +148,40 @@ def main():
     stream = None
     if use_dist:
         stream = torch.cuda.current_stream().cuda_stream   # run on torch's stream so the gather is ordered behind align
-    W_BAND, Z = 751, 400
-    scores = agatha_amd.Scores.make(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND)
+    W_BAND, Z = cfg["w"], cfg["z"]
+    scores = agatha_amd.Scores.make(s=3, z=Z, w=W_BAND, **cfg["scoring"])
+    strong = a.scaling == "strong"
 
-    qs, ts = workload.cfg_c1(n=a.pairs, seed=0xA6A70001 + rank)
+    # weak scaling: every rank has its own batch (own seed); strong scaling: every rank builds the SAME batch and keeps its
+    # share of the LPT partition by nominal cells (agatha_amd/shard.py) -- no data-path exchange, results gathered at the end
+    qs, ts = getattr(workload, cfg["gen"])(n=a.pairs, seed=0xA6A70000 + int(a.config[1]) + (0 if strong else rank))
     qb, qo, ql = workload.make_batch(qs)
     tb, to, tl = workload.make_batch(ts)
     del qs, ts
-    cells = workload.nominal_cells_total(ql, tl, W_BAND)
+    from agatha_amd import shard
+    full = (qb, tb, qo, to, ql, tl)
+    mine = None
+    imbalance = None
+    if strong:
+        cost = shard.nominal_cells(ql, tl, W_BAND)
+        parts = shard.lpt_partition(cost, world)
+        loads = np.array([int(cost[p].sum()) for p in parts], np.float64)
+        imbalance = float(loads.max() / loads.mean())
+        mine = parts[rank]
+        total_batch_cells, total_batch_pairs = float(cost.sum()), float(len(ql))
+        qb, tb, qo, to, ql, tl = shard.take_pairs(qb, tb, qo, to, ql, tl, mine)
+    cells = int(shard.nominal_cells(ql, tl, W_BAND).sum())
     abytes = algorithmic_bytes(ql, tl)
 
     b = eng.batch(qb, tb, qo, to, ql, tl)
-    res_t = gathered = None
+    res_t = gathered = idx_t = None
     if use_dist:
         res_t = torch.empty((3, b.n), dtype=torch.int32, device="cuda")
-        gathered = torch.empty((world, 3, b.n), dtype=torch.int32, device="cuda")
         b.use_result_pointers([res_t[k].data_ptr() for k in range(3)])
+        if strong:
+            idx_t = torch.from_numpy(np.asarray(mine, np.int64)).cuda()
+        else:
+            gathered = torch.empty((world, 3, b.n), dtype=torch.int32, device="cuda")
     b.upload(stream)
     eng.synchronize() if stream is None else torch.cuda.synchronize()
 
@@ -157,6 +194,8 @@ def main():
         b.align(scores, stream)
         if i is not None:
             eng.set_kernel_events(None, None)
+        if use_dist and strong:
+            return shard.gather_results_tensor(res_t, idx_t, len(full[4]), dist, torch)     # RCCL: 16 B per pair, input order restored
         if use_dist:
             dist.all_gather_into_tensor(gathered, res_t)       # RCCL: 12 B per pair, the only exchange
         else:
@@ -173,8 +212,9 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
+    last = None
     for i in range(a.steps):
-        step(i)
+        last = step(i)
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -186,15 +226,16 @@ def main():
         total_cells, total_pairs = float(tc[0].item()), float(tc[1].item())
     else:
         total_cells, total_pairs = float(cells), float(b.n)
+    strong_check = None
+    if strong:
+        total_cells, total_pairs = total_batch_cells, total_batch_pairs
+        if use_dist and rank == 0 and last is not None:
+            # rank 0 aligns the WHOLE batch alone once (untimed) and compares it with what the N ranks gathered
+            ref = eng.align_host_batch(*full, scores)
+            got = last.cpu().numpy()
+            same = int(sum(int(all(int(ref[j][i]) == int(got[j][i]) for j in range(3))) for i in range(len(full[4]))))
+            strong_check = f"{same}/{len(full[4])} pairs identical to the same batch aligned on one GPU"
 
-    # HBM bytes per launch measured with rocprofv3 PMC counters in a separate profiled run of this same command
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-        if pm.get("pairs") == a.pairs:
-            traffic = float(pm["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        pass
     kinds = b.pair_kinds(stream)            # how the last step's pairs were routed between the kernels
     sched = b.schedule_info(stream)         # (static preemptive schedule used, steps per lane group, lane groups used)
     kms = [eng.elapsed_ms(e0, e1) for e0, e1 in kev] if a.steps else [float("nan")]
@@ -202,24 +243,39 @@ def main():
     G, S = eng.last_config()
     kind, Gd, Sd = b.kernel_choice(stream)  # which candidate kernel the device picked for the plain pairs
     kname = f"agatha::align16_kernel<{Gd},{Sd // 2}>" if kind == "int16" else f"agatha::align_kernel<{Gd},{Sd},false>"
+    # HBM bytes per launch measured with rocprofv3 PMC counters in a separate profiled run of this same command
+    # (profiles/latest_pmc.json, written by tools/collate_profile.py); only quoted when it was taken on the kernel, the
+    # workload and the schedule that just ran -- a stale file gives null, not a wrong number
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        same_kernel = pm.get("kernel", "").replace(" ", "").startswith(kname.rstrip(">").replace(" ", "") + ",") or \
+            pm.get("kernel", "").replace(" ", "") == kname.replace(" ", "")
+        if pm.get("pairs") == a.pairs and pm.get("config", "C1") == a.config and same_kernel and not strong and \
+                bool(pm.get("preemptive_schedule", False)) == bool(sched[0]):
+            traffic = float(pm["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
 
     if rank == 0:
         ms_per_step = elapsed / max(a.steps, 1) * 1e3
         out = {
-            "metric": "GCUPS (banded DP cells/s), 10 kb ONT pairs, band=751, z=400",
+            "metric": "GCUPS (banded DP cells/s), 10 kb ONT pairs, band=751, z=400" if a.config == "C1" else
+                      f"GCUPS (banded DP cells/s), BASELINE.json config {a.config}, band={W_BAND}, z={Z}",
             "value": total_cells * a.steps / elapsed / 1e9,
             "unit": "GCUPS",
             "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": kind,
             "data": "synthetic",
-            "config": {"workload": f"C1: {a.pairs} synthetic ONT-like pairs per GPU, ~10 kb (8-12 kb), "
-                                   f"sub 3% ins 3% del 4%, m2 x4 q4 r2 w751 z400 s3 (BASELINE.json configs[1])",
-                       "pairs_per_gpu": a.pairs, "lanes_per_pair": Gd, "slots_per_lane": Sd, "kernel": kname,
+            "config": {"workload": f"{a.config}: {a.pairs} {cfg['text']}, " + ("ONE batch sharded over the GPUs (LPT by nominal cells)" if strong else "per GPU") +
+                                   f", m{cfg['scoring']['m']} x{cfg['scoring']['x']} q{cfg['scoring']['q']} r{cfg['scoring']['r']} w{W_BAND} z{Z} s3 "
+                                   f"(BASELINE.json configs[{int(a.config[1])}])",
+                       "pairs_per_gpu": b.n, "shard_imbalance_max_over_mean": imbalance, "strong_scaling_check": strong_check, "lanes_per_pair": Gd, "slots_per_lane": Sd, "kernel": kname,
                        "int32_fallback_kernel": f"agatha::align_kernel<{G},{S}>",
                        "pairs_plain_other_letters_int32_takeover_rank0": list(kinds),
                        "preemptive_schedule_rank0": {"used": sched[0], "steps_per_lane_group": sched[1], "lane_groups": sched[2]},
@@ -243,7 +299,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             gpu_res = tuple(np.array(b.res_host[j][:b.n]) for j in range(3))      # downloaded by the last step
-            out["cpu_baseline"] = cpu_baseline(qb, tb, qo, to, ql, tl, dict(m=2, x=4, q=4, r=2, s=3, z=Z, w=W_BAND), W_BAND,
+            out["cpu_baseline"] = cpu_baseline(qb, tb, qo, to, ql, tl, dict(s=3, z=Z, w=W_BAND, **cfg["scoring"]), W_BAND,
                                                gpu_res=gpu_res)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)

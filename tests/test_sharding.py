@@ -74,3 +74,61 @@ def test_two_process_gloo_gather_restores_input_order():
         ret = m.dict()
         mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {0: True, 1: True}
+
+
+def _strong_worker(rank, world, port, ret):
+    """The strong-scaling path of bench.py (--scaling strong) over gloo: LPT partition of ONE batch, every rank aligns
+    its share (the oracle stands in for the GPU here), shard.gather_results_tensor restores input order on every rank."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    qs, ts = synth.cfg_c4(n=97, seed=11, lo=50, hi=2500)
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    P = O.make_params(w=100, z=100)
+    cost = shard.nominal_cells(ql, tl, 100)
+    parts = shard.lpt_partition(cost, world)
+    loads = np.array([cost[p].sum() for p in parts])
+    sub = shard.take_pairs(qb, tb, qo, to, ql, tl, parts[rank])
+    local = torch.from_numpy(np.stack(O.align_batch(*sub, P, wide=True)).astype(np.int32))
+    full = shard.gather_results_tensor(local, torch.from_numpy(parts[rank]), len(ql), dist, torch).numpy()
+    exp = np.stack(O.align_batch(qb, tb, qo, to, ql, tl, P, wide=True))
+    ret[rank] = bool((full == exp).all()) and bool(loads.max() <= loads.mean() * 1.05 + cost.max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_path_two_process_gloo():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_strong_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}
+
+
+def test_fasta_index_reads_only_byte_ranges(tmp_path):
+    """agatha_amd.multi_gpu: the vectorised FASTA index (offsets, op codes, lengths without decoding a sequence) and the
+    per-record reads agree with the plain sequential reader, for ragged line widths, CRLF, empty lines and every op code."""
+    from agatha_amd import multi_gpu as M
+    rng = np.random.default_rng(4)
+    recs = [(">", b""), ("<", b"A")] + [("></+"[k % 4], synth.random_seq(rng, int(rng.integers(1, 700))).tobytes()) for k in range(60)]
+    for variant in range(3):
+        path = tmp_path / f"v{variant}.fa"
+        with open(path, "wb") as f:
+            for k, (op, s) in enumerate(recs):
+                eol = b"\r\n" if variant == 1 else b"\n"
+                f.write(op.encode() + b"rec%d extra text" % k + eol)
+                width = [61, 80, 7][variant]
+                for i in range(0, len(s), width):
+                    f.write(s[i:i + width] + eol)
+                if variant == 2 and k % 5 == 0:
+                    f.write(eol)                                   # empty line
+            if variant == 0:
+                f.seek(-1, 2); f.truncate()                        # no newline at the end of the file
+        seqs, ops = M.read_fasta(str(path))
+        iops, start, end, length = M.fasta_index(str(path), chunk=997)
+        assert (iops == ops).all() and length.tolist() == [len(s) for s in seqs]
+        ids = [0, 1, 5, 17, 61]
+        assert M.read_records(str(path), start, end, ids) == [seqs[i] for i in ids]

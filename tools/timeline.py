@@ -11,7 +11,7 @@ qb, qo, ql = workload.make_batch(qs); tb, to, tl = workload.make_batch(ts)
 b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); eng.synchronize()
 sc = agatha_amd.Scores.make()
 agatha_amd.set_debug_option("timeline", 1)
-modes = [(0, -1, 8), (1, -1, 8), (0, 0, 8), (1, 15, 8)]
+modes = [(0, -1, 8), (0, -1, 8)]
 for nomig, pb, duty in modes:
     agatha_amd.set_debug_option("no_migrate", nomig)
     agatha_amd.set_debug_option("prio_slice", pb)
@@ -37,6 +37,15 @@ for nomig, pb, duty in modes:
     cukey = xcc * 10000 + se * 100 + cu
     u2, c2 = np.unique(cukey, return_counts=True)
     print("  distinct CUs:", len(u2), "waves per CU histogram:", dict(zip(*np.unique(c2, return_counts=True))))
+    for x in range(8):
+        m = xcc == x
+        if m.any(): print("   xcc %d: waves %d  end min %.0f median %.0f max %.0f  us/step median %.2f" % (x, m.sum(), en[m].min(), np.median(en[m]), en[m].max(), np.median(us_per_step[m])))
+    for q in (0, 1):
+        m = (wid & 1) == q
+        print("   slot %d: end min %.0f median %.0f max %.0f" % (q, en[m].min(), np.median(en[m]), en[m].max()))
+    # per CU: spread of the end times of its 8 waves, and of the CU means
+    cu_mean = np.array([en[cukey == u].mean() for u in u2]); cu_max = np.array([en[cukey == u].max() for u in u2])
+    print("   per-CU mean end: min %.0f median %.0f max %.0f ; per-CU max end: min %.0f median %.0f max %.0f" % (cu_mean.min(), np.median(cu_mean), cu_mean.max(), cu_max.min(), np.median(cu_max), cu_max.max()))
     # speed against how many waves share the SIMD
     per = dict(zip(uniq, cnt))
     share = np.array([per[k] for k in key])
