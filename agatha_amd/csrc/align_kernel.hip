@@ -640,6 +640,63 @@ seq_ops_kernel(const uint8_t* __restrict__ unpacked, uint32_t* __restrict__ pack
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Start positions (the reference declares query_batch_start / target_batch_start, gasal.h:89-90, and leaves them NULL,
+// res.cpp:27-28): the same banded extension is run BACKWARDS from the end cell, on the reversed prefixes q[0..qend],
+// t[0..tend].  reverse_prefix_kernel writes those prefixes (packed, one wave per sequence, at the sequence's own offset
+// in a second packed buffer) and their lengths end + 1; starts_kernel turns the backward run's end cell into the start.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+reverse_prefix_kernel(const uint32_t* __restrict__ packed, uint32_t* __restrict__ rev, const uint32_t* __restrict__ offsets,
+                      const int32_t* __restrict__ ends, uint32_t* __restrict__ rev_lens, uint32_t n)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t s = wave; s < n; s += nwaves) {
+        const int32_t e = ends[s];
+        const uint32_t len = e >= 0 ? (uint32_t)e + 1u : 0u;
+        if (lane == 0) rev_lens[s] = len;
+        const uint32_t* src = packed + (offsets[s] >> 3);
+        uint32_t* dst = rev + (offsets[s] >> 3);
+        const uint32_t nw = (len + 7u) >> 3;
+        for (uint32_t wi = lane; wi < nw; wi += 64u) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint32_t p = 8u * wi + k;
+                uint32_t c = N_VALUE;
+                if (p < len) { const uint32_t q = len - 1u - p; c = (src[q >> 3] >> (28u - 4u * (q & 7u))) & 15u; }
+                v |= c << (28u - 4u * k);
+            }
+            dst[wi] = v;
+        }
+    }
+}
+
+__global__ void starts_kernel(const int32_t* __restrict__ qend, const int32_t* __restrict__ tend, const int32_t* __restrict__ bq,
+                              const int32_t* __restrict__ bt, int32_t* __restrict__ qstart, int32_t* __restrict__ tstart, uint32_t n)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { qstart[t] = qend[t] - bq[t]; tstart[t] = tend[t] - bt[t]; }
+}
+
+hipError_t launch_reverse_prefix(const uint32_t* packed, uint32_t* rev, const uint32_t* offsets, const int32_t* ends,
+                                 uint32_t* rev_lens, uint32_t n, hipStream_t st)
+{
+    uint32_t blocks = (n + 3u) / 4u;
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks < 1u) blocks = 1u;
+    hipLaunchKernelGGL(reverse_prefix_kernel, dim3(blocks), dim3(256), 0, st, packed, rev, offsets, ends, rev_lens, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_starts(const int32_t* qend, const int32_t* tend, const int32_t* bq, const int32_t* bt, int32_t* qstart,
+                         int32_t* tstart, uint32_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(starts_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, qend, tend, bq, bt, qstart, tstart, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_seq_ops(const uint8_t* unpacked, uint32_t* packed, const uint32_t* lens, const uint32_t* offsets,
                           const uint8_t* ops, uint32_t n, hipStream_t st)
 {

@@ -282,6 +282,45 @@ int agatha_amd_get_debug_option(const char* name, int* value)
     return AGATHA_AMD_EINVAL;
 }
 
+size_t agatha_amd_starts_scratch_bytes(uint32_t query_batch_bytes, uint32_t target_batch_bytes, uint32_t max_n_alns)
+{
+    // reversed packed prefixes of both sides (4 bit per base of the unpacked layout), their lengths, the backward results
+    return round_up((size_t)query_batch_bytes / 2 + 16) + round_up((size_t)target_batch_bytes / 2 + 16) +
+           5 * round_up(sizeof(uint32_t) * (size_t)max_n_alns);
+}
+
+int agatha_amd_align_starts(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
+                            const uint32_t* d_query_offsets, const uint32_t* d_target_offsets, uint32_t n_alns,
+                            uint32_t query_batch_bytes, uint32_t target_batch_bytes, uint32_t max_query_len, uint32_t max_target_len,
+                            const agatha_amd_scores* sc, const int32_t* d_query_batch_end, const int32_t* d_target_batch_end,
+                            int32_t* d_query_batch_start, int32_t* d_target_batch_start, void* d_workspace,
+                            size_t workspace_bytes, void* d_scratch, size_t scratch_bytes)
+{
+    if (!d_packed_query || !d_packed_target || !d_query_offsets || !d_target_offsets || !sc || !d_query_batch_end ||
+        !d_target_batch_end || !d_query_batch_start || !d_target_batch_start || !d_workspace || !d_scratch || n_alns == 0)
+        return AGATHA_AMD_EINVAL;
+    if (scratch_bytes < agatha_amd_starts_scratch_bytes(query_batch_bytes, target_batch_bytes, n_alns)) return AGATHA_AMD_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)d_scratch;
+    uint32_t* rq = (uint32_t*)p;   p += round_up((size_t)query_batch_bytes / 2 + 16);
+    uint32_t* rt = (uint32_t*)p;   p += round_up((size_t)target_batch_bytes / 2 + 16);
+    const size_t arr = round_up(sizeof(uint32_t) * (size_t)n_alns);
+    uint32_t* rql = (uint32_t*)p;  p += arr;
+    uint32_t* rtl = (uint32_t*)p;  p += arr;
+    int32_t* bs = (int32_t*)p;     p += arr;
+    int32_t* bq = (int32_t*)p;     p += arr;
+    int32_t* bt = (int32_t*)p;
+    HIPCHK(agatha::launch_reverse_prefix(d_packed_query, rq, d_query_offsets, d_query_batch_end, rql, n_alns, st));
+    HIPCHK(agatha::launch_reverse_prefix(d_packed_target, rt, d_target_offsets, d_target_batch_end, rtl, n_alns, st));
+    agatha_amd_scores back = *sc;
+    back.z_threshold = -1;                      // the alignment is known to exist: no z-drop on the way back
+    const int rc = agatha_amd_align(stream, rq, rt, rql, rtl, d_query_offsets, d_target_offsets, n_alns, max_query_len, max_target_len,
+                                    &back, bs, bq, bt, d_workspace, workspace_bytes);
+    if (rc != 0) return rc;
+    HIPCHK(agatha::launch_starts(d_query_batch_end, d_target_batch_end, bq, bt, d_query_batch_start, d_target_batch_start, n_alns, st));
+    return 0;
+}
+
 void agatha_amd_set_kernel_events(void* ev_begin, void* ev_end) { g_ev0 = (hipEvent_t)ev_begin; g_ev1 = (hipEvent_t)ev_end; }
 
 void agatha_amd_last_config(int* G, int* S) { if (G) *G = g_lastG; if (S) *S = g_lastS; }

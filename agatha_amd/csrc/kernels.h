@@ -84,6 +84,10 @@ hipError_t launch_sort(const uint32_t* qlens, const uint32_t* tlens, int n, uint
                        uint32_t* order, float* totals, hipStream_t st);
 hipError_t launch_seq_ops(const uint8_t* unpacked, uint32_t* packed, const uint32_t* lens, const uint32_t* offsets,
                           const uint8_t* ops, uint32_t n, hipStream_t st);
+hipError_t launch_reverse_prefix(const uint32_t* packed, uint32_t* rev, const uint32_t* offsets, const int32_t* ends,
+                                 uint32_t* rev_lens, uint32_t n, hipStream_t st);
+hipError_t launch_starts(const int32_t* qend, const int32_t* tend, const int32_t* bq, const int32_t* bt, int32_t* qstart,
+                         int32_t* tstart, uint32_t n, hipStream_t st);
 hipError_t launch_pack(const uint8_t* unpacked, uint32_t nbytes, uint32_t* packed, hipStream_t st);
 
 }  // namespace agatha

@@ -71,6 +71,10 @@ def load_library():
     lib.agatha_amd_seq_ops.argtypes = [vp, vp, u32p, u32p, u32p, vp, C.c_uint32]
     lib.agatha_amd_align.argtypes = [vp, u32p, u32p, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.POINTER(Scores), i32p, i32p, i32p, vp, C.c_size_t]
+    lib.agatha_amd_starts_scratch_bytes.restype = C.c_size_t
+    lib.agatha_amd_starts_scratch_bytes.argtypes = [C.c_uint32] * 3
+    lib.agatha_amd_align_starts.argtypes = [vp, u32p, u32p, u32p, u32p] + [C.c_uint32] * 5 + [C.POINTER(Scores)] + [i32p] * 4 + \
+        [vp, C.c_size_t, vp, C.c_size_t]
     lib.agatha_amd_set_kernel_events.argtypes = [vp, vp]
     lib.agatha_amd_set_kernel_events.restype = None
     lib.agatha_amd_last_config.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -103,7 +107,7 @@ def load_library():
 EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack", "agatha_amd_pack_host",
-    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_starts_scratch_bytes", "agatha_amd_align_starts", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -264,6 +268,30 @@ class DeviceBatch:
                                        self.max_tlen if use_len_hint else 0, C.byref(scores),
                                        self.d_res[0].ptr, self.d_res[1].ptr, self.d_res[2].ptr,
                                        self.d_ws.ptr, self.ws_bytes))
+
+    def align_starts(self, scores, stream=None):
+        """Start positions of the alignments the last align() found (agatha_amd_align_starts): returns two int32 arrays
+        (query start, target start); synchronises."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        m = self.d_meta
+        nb = lib.agatha_amd_starts_scratch_bytes(self.qbytes, self.tbytes, self.n)
+        scratch = _DevBuf(lib, nb)
+        out = [_DevBuf(lib, 4 * self.n) for _ in range(2)]
+        try:
+            _chk(lib, lib.agatha_amd_align_starts(st, self.d_pk_q.ptr, self.d_pk_t.ptr, m[0].ptr, m[1].ptr, self.n, self.qbytes,
+                                                  self.tbytes, self.max_qlen, self.max_tlen, C.byref(scores), self.d_res[1].ptr,
+                                                  self.d_res[2].ptr, out[0].ptr, out[1].ptr, self.d_ws.ptr, self.ws_bytes,
+                                                  scratch.ptr, nb))
+            h = np.zeros((2, self.n), np.int32)
+            for k in range(2):
+                _chk(lib, lib.agatha_amd_memcpy_d2h_async(st, h[k].ctypes.data, out[k].ptr, 4 * self.n))
+            _chk(lib, lib.agatha_amd_stream_synchronize(st))
+            return h[0], h[1]
+        finally:
+            scratch.free()
+            for o in out:
+                o.free()
 
     def kernel_choice(self, stream=None):
         """("int32" | "int16", lanes per pair, slots per lane) of the kernel the device chose for the plain pairs."""

@@ -5,13 +5,14 @@
 // Options are scanned over argv[1 .. argc-4]; the last two (three with -p) arguments are positional; argc < 4 is
 // refused; unknown single letters are ignored.  -b/-t are accepted and ignored by the HIP engine (its launch shape
 // is derived from the band); -c (extension) enables the reverse/complement op codes of the FASTA headers; -g N
-// (extension) spreads the host threads over N GPUs; -k (extension) packs on the host (isPacked storages, ctors.cpp:65-73).
+// (extension) spreads the host threads over N GPUs; -k (extension) packs on the host (isPacked storages, ctors.cpp:65-73);
+// -S (extension) fills the start members of the results (the reference declares them and leaves them NULL).
 #include "../../include/gasal_header.h"
 
 Parameters::Parameters(int argc_, char** argv_)
     : sa(2), sb(4), gapo(4), gape(2), print_out(0), n_threads(1), slice_width(3), z_threshold(400), band_width(751),
       kernel_block_num(256), kernel_thread_num(256), kernel_align_num(8192), isPacked(false),
-      isReverseComplement(false), n_gpus(1), argc(argc_), argv(argv_)
+      isReverseComplement(false), start_pos(0), n_gpus(1), argc(argc_), argv(argv_)
 {
 }
 
@@ -68,6 +69,7 @@ void Parameters::help()
     std::cerr << "         -n INT    number of CPU threads [" << n_threads << "]" << std::endl;
     std::cerr << "         -c        apply the reverse/complement codes of the FASTA header characters (> < / +)" << std::endl;
     std::cerr << "         -k        pack the sequences on the host and ship pre-packed batches (isPacked): half the H2D bytes" << std::endl;
+    std::cerr << "         -S        also compute and print the start positions (query_batch_start / target_batch_start)" << std::endl;
     std::cerr << "         -g INT    spread the CPU threads over this many GPUs [" << n_gpus << "]" << std::endl;
     std::cerr << "         --help, -h : displays this message." << std::endl;
     std::cerr << "Single-pack multi-Parameters (e.g. -sp) is not supported." << std::endl;
@@ -98,6 +100,7 @@ void Parameters::parse()
             case 'n': n_threads = next_int(c); break;
             case 'g': n_gpus = next_int(c); break;
             case 'k': isPacked = true; break;
+            case 'S': start_pos = 1; break;
             case 's': slice_width = next_int(c); break;
             case 'z': z_threshold = next_int(c); break;
             case 'w': band_width = next_int(c); break;

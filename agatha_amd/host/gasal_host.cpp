@@ -74,21 +74,30 @@ void free_device_meta(gasal_gpu_storage_t* s)
 void gasal_copy_subst_scores(gasal_subst_scores* subst) { g_scores = *subst; }
 
 // ------------------------------------------------------------------------------------------------ results
-gasal_res_t* gasal_res_new_host(uint32_t max_n_alns, Parameters*)
+// (the start members: NULL as in the reference, res.cpp:27-28,76-77, unless params->start_pos asks for them)
+gasal_res_t* gasal_res_new_host(uint32_t max_n_alns, Parameters* params)
 {
     gasal_res_t* r = (gasal_res_t*)calloc(1, sizeof(gasal_res_t));
     if (!r) { fprintf(stderr, "Malloc error on res host "); exit(1); }
     r->aln_score = pin_alloc<int32_t>(max_n_alns);
     r->query_batch_end = pin_alloc<int32_t>(max_n_alns);
     r->target_batch_end = pin_alloc<int32_t>(max_n_alns);
+    if (params && params->start_pos) {
+        r->query_batch_start = pin_alloc<int32_t>(max_n_alns);
+        r->target_batch_start = pin_alloc<int32_t>(max_n_alns);
+    }
     return r;
 }
-gasal_res_t* gasal_res_new_device_cpy(uint32_t max_n_alns, Parameters*)
+gasal_res_t* gasal_res_new_device_cpy(uint32_t max_n_alns, Parameters* params)
 {
     gasal_res_t* r = (gasal_res_t*)calloc(1, sizeof(gasal_res_t));
     r->aln_score = dev_alloc<int32_t>(max_n_alns);
     r->query_batch_end = dev_alloc<int32_t>(max_n_alns);
     r->target_batch_end = dev_alloc<int32_t>(max_n_alns);
+    if (params && params->start_pos) {
+        r->query_batch_start = dev_alloc<int32_t>(max_n_alns);
+        r->target_batch_start = dev_alloc<int32_t>(max_n_alns);
+    }
     return r;
 }
 // The reference keeps a second, device-resident copy of the struct for its kernel to dereference; the HIP kernel
@@ -309,6 +318,7 @@ void gasal_destroy_streams(gasal_gpu_storage_v* vec, Parameters* params)
         pin_free(s->host_query_batch_offsets); pin_free(s->host_target_batch_offsets);
         pin_free(s->host_query_batch_lens); pin_free(s->host_target_batch_lens);
         free_device_meta(s);
+        dev_free(s->starts_scratch);
         dev_free(s->unpacked_query_batch); dev_free(s->unpacked_target_batch);
         if (!params->isPacked) { dev_free(s->packed_query_batch); dev_free(s->packed_target_batch); }
         if (s->ev_begin) CHK(agatha_amd_event_destroy(s->ev_begin));
@@ -448,10 +458,35 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
     CHK(rc);
     if (params->print_out) { CHK(agatha_amd_event_record(s->ev_end, s->str)); s->timing_pending = 1; s->timing_params = params; }
 
+    if (params->start_pos) {
+        // start positions (extension; the reference copies them back only if they are not NULL, gasal_align.cu:256-260, and they
+        // always are): the same extension run backwards from every end cell, agatha_amd_align_starts
+        const size_t need = agatha_amd_starts_scratch_bytes(s->gpu_max_query_batch_bytes, s->gpu_max_target_batch_bytes, s->gpu_max_n_alns);
+        if (s->starts_scratch_bytes < need) {
+            CHK(agatha_amd_stream_synchronize(s->str));
+            dev_free(s->starts_scratch);
+            s->starts_scratch = dev_alloc<uint8_t>(need);
+            s->starts_scratch_bytes = need;
+        }
+        if (!s->device_cpy->query_batch_start || !s->host_res->query_batch_start) {
+            fprintf(stderr, "[GASAL ERROR:] start_pos was set after the result objects were created\n");
+            exit(EXIT_FAILURE);
+        }
+        CHK(agatha_amd_align_starts(s->str, s->packed_query_batch, s->packed_target_batch, s->query_batch_offsets,
+                                    s->target_batch_offsets, actual_n_alns, actual_query_batch_bytes, actual_target_batch_bytes,
+                                    max_q, max_t, &sc, s->device_cpy->query_batch_end, s->device_cpy->target_batch_end,
+                                    s->device_cpy->query_batch_start, s->device_cpy->target_batch_start, s->workspace,
+                                    s->workspace_bytes, s->starts_scratch, s->starts_scratch_bytes));
+    }
+
     const size_t rb = (size_t)actual_n_alns * sizeof(int32_t);      // gasal_align.cu:253-266
     CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->aln_score, s->device_cpy->aln_score, rb));
     CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->query_batch_end, s->device_cpy->query_batch_end, rb));
     CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->target_batch_end, s->device_cpy->target_batch_end, rb));
+    if (s->host_res->query_batch_start && s->device_cpy->query_batch_start)
+        CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->query_batch_start, s->device_cpy->query_batch_start, rb));
+    if (s->host_res->target_batch_start && s->device_cpy->target_batch_start)
+        CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->target_batch_start, s->device_cpy->target_batch_start, rb));
     s->is_free = 0;
 }
 

@@ -142,9 +142,14 @@ int main(int argc, char** argv)
 #pragma omp critical
                         {
                             const gasal_res_t* r = slot[z].st->host_res;
-                            for (int j = 0; j < slot[z].n; j++)
+                            for (int j = 0; j < slot[z].n; j++) {
                                 std::cout << r->aln_score[j] << "\tquery_batch_end=" << r->query_batch_end[j]
-                                          << "\ttarget_batch_end=" << r->target_batch_end[j] << std::endl;
+                                          << "\ttarget_batch_end=" << r->target_batch_end[j];
+                                if (args->start_pos)        // -S (extension)
+                                    std::cout << "\tquery_batch_start=" << r->query_batch_start[j] << "\ttarget_batch_start="
+                                              << r->target_batch_start[j];
+                                std::cout << std::endl;
+                            }
                         }
                     }
                     batches_done++;

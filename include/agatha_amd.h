@@ -93,6 +93,22 @@ int agatha_amd_align(void* stream,
                      int32_t* d_aln_score, int32_t* d_query_batch_end, int32_t* d_target_batch_end,
                      void* d_workspace, size_t workspace_bytes);
 
+/* Start positions of the alignments agatha_amd_align() found: fills the result members the reference declares and leaves
+ * NULL (query_batch_start / target_batch_start, gasal.h:89-90, res.cpp:27-28; GASAL2's WITH_START, gasal.h:36).  The same
+ * banded extension is run BACKWARDS from every end cell -- on the reversed prefixes q[0..query_end], t[0..target_end],
+ * z-drop off -- and the cell it ends in is where the best-scoring alignment that ends in (query_end, target_end) begins
+ * (0-based inclusive, like the ends).  Call after agatha_amd_align() on the same stream, with its end arrays; the packed
+ * batches must still be resident.  query_batch_bytes / target_batch_bytes: sizes of the UNPACKED layout (what
+ * gasal_aln_async takes).  d_scratch: agatha_amd_starts_scratch_bytes() of device memory; d_workspace as for
+ * agatha_amd_align (the same one may be used).  Costs about one more agatha_amd_align of the batch. */
+size_t agatha_amd_starts_scratch_bytes(uint32_t query_batch_bytes, uint32_t target_batch_bytes, uint32_t max_n_alns);
+int agatha_amd_align_starts(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
+                            const uint32_t* d_query_offsets, const uint32_t* d_target_offsets, uint32_t n_alns,
+                            uint32_t query_batch_bytes, uint32_t target_batch_bytes, uint32_t max_query_len, uint32_t max_target_len,
+                            const agatha_amd_scores* scores, const int32_t* d_query_batch_end, const int32_t* d_target_batch_end,
+                            int32_t* d_query_batch_start, int32_t* d_target_batch_start, void* d_workspace,
+                            size_t workspace_bytes, void* d_scratch, size_t scratch_bytes);
+
 /* Optional: a hipEvent_t pair (as void*) that the NEXT agatha_amd_align() calls of this thread record directly
  * around the alignment kernel launch (excluding the sort); pass NULLs to switch it off.  Used by bench.py for
  * the per-kernel duration of the roofline line. */

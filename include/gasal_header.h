@@ -44,7 +44,8 @@ struct host_batch {
 };
 typedef struct host_batch host_batch_t;
 
-/* result arrays; start / cigar members exist for layout compatibility and stay NULL (gasal.h:85-94, res.cpp:27-28) */
+/* result arrays (gasal.h:85-94).  The reference leaves the start members NULL (res.cpp:27-28); here they are allocated and
+ * filled when params->start_pos is set (extension, CLI flag -S: GASAL2's WITH_START, gasal.h:36); cigar members stay NULL */
 struct gasal_res {
     int32_t* aln_score;
     int32_t* query_batch_end;
@@ -116,6 +117,8 @@ typedef struct {
     void* ev_begin;                     /* hipEvent_t pair for the -p timing mode */
     void* ev_end;
     int timing_pending;
+    void* starts_scratch;               /* device scratch of agatha_amd_align_starts (only with params->start_pos) */
+    size_t starts_scratch_bytes;
     void* timing_params;                /* Parameters* of the batch in flight: its raw_file gets the -p line */
     int is_free;
     int id;
@@ -146,6 +149,7 @@ class Parameters {
     int32_t kernel_block_num, kernel_thread_num, kernel_align_num;
     bool isPacked;
     bool isReverseComplement;
+    int start_pos;                      /* extension (-S): also compute query_batch_start / target_batch_start (WITH_START, gasal.h:36) */
     int n_gpus;                         /* extension (-g): host threads are spread over this many GPUs (gasal_set_device) */
     std::string query_batch_fasta_filename, target_batch_fasta_filename, raw_filename;
     std::ifstream query_batch_fasta, target_batch_fasta;

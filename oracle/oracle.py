@@ -143,6 +143,18 @@ def align_pairs(queries, targets, params, **kw):
     return align_batch(qb, tb, qo, to, ql, tl, params, **kw)
 
 
+def start_positions(queries, targets, params, qend, tend, threads=1):
+    """Start positions (the reference declares query_batch_start / target_batch_start, gasal.h:89-90, and leaves them NULL,
+    res.cpp:27-28; GASAL2's WITH_START idea, gasal.h:36): the SAME banded extension run backwards from the end cell --
+    on the reversed prefixes q[0..qend], t[0..tend], z-drop off -- ends in the cell where the best-scoring alignment that
+    ends in (qend, tend) begins.  Returns (query_start, target_start, backward_score)."""
+    rq = [bytes(q[:int(e) + 1])[::-1] for q, e in zip(queries, qend)]
+    rt = [bytes(t[:int(e) + 1])[::-1] for t, e in zip(targets, tend)]
+    back = Params(params.match, params.mismatch, params.gap_open, params.gap_extend, params.slice_width, -1, params.band_width)
+    s, q, t = align_pairs(rq, rt, back, wide=True, model=MODEL_SLICES, threads=threads)
+    return np.asarray(qend, np.int32) - q, np.asarray(tend, np.int32) - t, s
+
+
 def pack(unpacked):
     unpacked = np.ascontiguousarray(unpacked, np.uint8)
     assert unpacked.size % 8 == 0

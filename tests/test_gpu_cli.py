@@ -174,3 +174,29 @@ def test_cli_prepacked_batches_through_the_gasal_api(tmp_path):
     # ops + pre-packed together are refused, as documented
     r = subprocess.run([MANUAL, "-p", "-k", "-c", "-w", "100", str(f1), str(f2), str(tmp_path / "r.log")], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "isPacked" in r.stderr
+
+
+def test_cli_start_positions(tmp_path):
+    """f4 through the GASAL API: `manual -p -S` allocates and fills host_res->query_batch_start / target_batch_start (NULL in
+    the reference, res.cpp:27-28) and prints them behind the ends."""
+    rng = np.random.default_rng(2)
+    qs, ts = synth.make_pairs(9, 120, lambda r: int(r.integers(30, 3000)))
+    qs = [synth.random_seq(rng, int(rng.integers(1, 30))).tobytes() + q if k % 2 else q for k, q in enumerate(qs)]
+    f1, f2, raw = tmp_path / "a.fa", tmp_path / "b.fa", tmp_path / "raw.log"
+    write_fasta(f1, qs, header=">")
+    write_fasta(f2, ts, header=">")
+    r = subprocess.run([MANUAL, "-p", "-S", "-w", "200", "-z", "300", "-a", "50", str(f1), str(f2), str(raw)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = []
+    for line in r.stdout.strip().splitlines():
+        f = line.split("\t")
+        assert [x.split("=")[0] for x in f[1:]] == ["query_batch_end", "target_batch_end", "query_batch_start", "target_batch_start"]
+        rows.append([int(f[0])] + [int(x.split("=")[1]) for x in f[1:]])
+    got = np.array(rows, np.int64)
+    P = O.make_params(w=200, z=300)
+    es, eq, et = O.align_pairs(qs, ts, P, wide=True, threads=4)
+    xq, xt, _ = O.start_positions(qs, ts, P, eq, et, threads=4)
+    exp = np.stack([es, eq, et, xq, xt], axis=1)
+    match_batches(got, [exp[k:k + 50] for k in range(0, 120, 50)])
+    assert (exp[:, 3] > 0).sum() > 30

@@ -241,3 +241,41 @@ def test_seq_ops_kernel_against_the_reference_as_written(eng):
             assert nib(ref[w0:w1])[:pad] == [14] * pad and nib(got[w0:w1])[len(s):] == [14] * pad
             n_diff += 1
     assert n_equal > 40 and n_diff > 40
+
+
+def test_start_positions_against_the_oracle(eng):
+    """f4: agatha_amd_align_starts (reverse-prefix kernel + the ordinary align kernels run backwards + starts kernel) against
+    the oracle's definition, on pairs with junk in front of either sequence, ragged lengths, z-dropped pairs (their end
+    cell lies before the break) and pairs without any positive score."""
+    import agatha_amd
+    rng = np.random.default_rng(8)
+    qs, ts = [], []
+    for k in range(300):
+        core = synth.random_seq(rng, int(rng.integers(1, 2500)))
+        rd = synth.mutate(rng, core, 0.03, 0.03, 0.04)
+        if rd.size == 0:
+            rd = synth.random_seq(rng, 1)
+        a, b = core.tobytes(), rd.tobytes()
+        if k % 3 == 1:
+            a = synth.random_seq(rng, int(rng.integers(1, 40))).tobytes() + a
+        if k % 3 == 2:
+            b = synth.random_seq(rng, int(rng.integers(1, 40))).tobytes() + b
+        if k % 7 == 0:
+            b = b[:len(b) // 2] + synth.random_seq(rng, len(b) // 2 + 1).tobytes()          # breaks: z-drop
+        qs.append(a); ts.append(b)
+    qs += [b"ACGT", b"A"]; ts += [b"TTTT", b"C"]
+    for p in (dict(m=2, x=4, q=4, r=2, s=3, z=100, w=64), dict(m=1, x=4, q=6, r=2, s=3, z=400, w=751)):
+        qb, qo, ql = O.make_batch(qs)
+        tb, to, tl = O.make_batch(ts)
+        P = O.make_params(**p)
+        es, eq, et = O.align_batch(qb, tb, qo, to, ql, tl, P, wide=True, threads=8)
+        xq, xt, _ = O.start_positions(qs, ts, P, eq, et, threads=8)
+        b = eng.batch(qb, tb, qo, to, ql, tl)
+        try:
+            b.upload(); b.pack(); b.align(_scores(p)); b.download()
+            gq, gt = b.align_starts(_scores(p))
+            assert (b.res_host[0] == es).all() and (b.res_host[1] == eq).all() and (b.res_host[2] == et).all()
+        finally:
+            b.free()
+        assert (gq == xq).all() and (gt == xt).all()
+        assert (gq > 0).sum() > 50 and (gt > 0).sum() > 50 and (gq >= 0).all() and (gq <= eq).all() and (gt <= et).all()

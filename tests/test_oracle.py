@@ -214,3 +214,19 @@ def test_seq_ops_reference_as_written_and_product_semantics():
         assert same == (len(s) % 8 == 0 or not (o & 1)), (len(s), int(o))
         n_diff += not same
     assert n_diff > 20
+
+
+def test_start_positions_definition():
+    """f4: the start of an alignment = where the same extension, run backwards from the end cell on the reversed prefixes,
+    ends (GASAL2's WITH_START idea, gasal.h:36; the reference declares the result members and leaves them NULL).  A clean
+    pair starts at (0, 0); junk in front of either sequence is skipped by the start, although the extension itself,
+    anchored at (0, 0), pays a gap for it."""
+    rng = np.random.default_rng(3)
+    core = synth.random_seq(rng, 400).tobytes()
+    junk = synth.random_seq(rng, 30).tobytes()
+    P = O.make_params(w=100, z=400)
+    qs, ts = [core, junk + core, core, b"ACGT"], [core, core, junk + core, b"TTTT"]
+    s, qe, te = O.align_pairs(qs, ts, P, wide=True)
+    qs_, ts_, back = O.start_positions(qs, ts, P, qe, te)
+    assert s.tolist()[0] == 800 and qs_.tolist() == [0, 30, 0, 0] and ts_.tolist() == [0, 0, 30, 0]
+    assert (back >= s).all() and back.tolist()[1] == 800
