@@ -560,7 +560,8 @@ __global__ void __launch_bounds__(256)
 exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__ packed_t,
               const uint32_t* __restrict__ qlens, const uint32_t* __restrict__ tlens,
               const uint32_t* __restrict__ qoffs, const uint32_t* __restrict__ toffs, uint8_t* __restrict__ exotic, int n,
-              unsigned int* __restrict__ kind_counts)
+              unsigned int* __restrict__ kind_counts, AlignParams P, long long score_limit,
+              int32_t* __restrict__ score, int32_t* __restrict__ qend, int32_t* __restrict__ tend)
 {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -578,9 +579,19 @@ exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict_
         for (uint32_t i = lane; i < nb; i += 64u) plain = plain && word_is_plain(b[i]);
         const bool all_plain = __all(plain), any_qn = __any(qn);
         if (lane == 0) {
-            const int kind = all_plain ? (any_qn ? 2 : 0) : 1;
+            int kind = all_plain ? (any_qn ? 2 : 0) : 1;
+            // kind 3: the scores this pair can reach do not fit the kernels' H << K keys (only possible when the caller
+            // gave no length hints: with hints the host refuses the whole call, AGATHA_AMD_ERANGE): no kernel takes it
+            const long long Q = ql, R = tlens[p], lmin = Q < R ? Q : R, lmax = Q > R ? Q : R;
+            const long long top = lmin * (P.match > 1 ? P.match : 1) + 16384 + 2ll * (P.band_width + 8) * P.gap_extend;
+            const long long per = P.mismatch > 2 * P.gap_extend ? P.mismatch : 2 * P.gap_extend;
+            const long long low = P.z_threshold < 0 ? lmax * (per > 1 ? per : 1) + P.gap_open + 16384 : 0;
+            if (top >= score_limit || low >= score_limit) {
+                kind = 3;
+                score[p] = INT_MIN; qend[p] = -1; tend[p] = -1;          // AGATHA_AMD_BAD_RESULT
+            }
             exotic[p] = (uint8_t)kind;
-            if (kind) atomicAdd(kind_counts + (kind - 1), 1u);
+            if (kind == 1 || kind == 2) atomicAdd(kind_counts + (kind - 1), 1u);
         }
     }
 }
@@ -591,7 +602,7 @@ hipError_t launch_exotic(const AlignLaunch& L, hipStream_t st)
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(exotic_kernel, dim3(blocks), dim3(256), 0, st, L.packed_q, L.packed_t, L.qlens, L.tlens, L.qoffs,
-                       L.toffs, L.exotic, L.n, L.kind_counts);
+                       L.toffs, L.exotic, L.n, L.kind_counts, L.p, L.score_limit, L.score, L.qend, L.tend);
     return hipGetLastError();
 }
 

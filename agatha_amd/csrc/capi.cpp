@@ -187,13 +187,20 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     if (max_target_len) window = std::min(window, ((long)max_target_len + 7) / 8);
     window = std::max(window, 1L);
     if (window > agatha::max_window_blocks()) return AGATHA_AMD_EBAND;
-    // scores are carried as H << K in int32: the largest possible score must stay below 2^(30-K)
-    {
-        const int K = agatha::key_bits_for_window((int)window);
-        const long lmax = (max_query_len && max_target_len) ? std::min<long>(max_query_len, max_target_len)
+    // scores are carried as H << K in int32: the largest possible score -- and, with z-drop off, the deepest negative one --
+    // must stay below 2^(30-K).  With length hints the whole call is refused here; without them (0 = unknown) the device
+    // checks every pair and writes AGATHA_AMD_BAD_RESULT for the ones that do not fit (exotic_kernel, kind 3).
+    const int Kbits = agatha::key_bits_for_window((int)window);
+    if (Kbits < 0) return AGATHA_AMD_ERANGE;
+    const long long score_limit = 1ll << (30 - Kbits);
+    if (max_query_len || max_target_len) {
+        const long lmin = (max_query_len && max_target_len) ? std::min<long>(max_query_len, max_target_len)
                           : (long)std::max(max_query_len, max_target_len);
-        const long top = std::max<long>(lmax, 1) * std::max(sc->match, 1) + 16384 + 2L * (sc->band_width + 8) * sc->gap_extend;
-        if (K < 0 || top >= (1L << (30 - K))) return AGATHA_AMD_ERANGE;
+        const long lmax = (long)std::max(max_query_len, max_target_len);
+        const long long top = (long long)std::max<long>(lmin, 1) * std::max(sc->match, 1) + 16384 + 2ll * (sc->band_width + 8) * sc->gap_extend;
+        const long long per = std::max(sc->mismatch, 2 * sc->gap_extend);
+        const long long low = sc->z_threshold < 0 ? (long long)lmax * std::max<long long>(per, 1) + sc->gap_open + 16384 : 0;
+        if (top >= score_limit || low >= score_limit) return AGATHA_AMD_ERANGE;
     }
 
     hipStream_t st = (hipStream_t)stream;
@@ -226,6 +233,7 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.num_cus = num_cus();
     L.exotic = exotic;
     L.kind_counts = queue + 12;
+    L.score_limit = score_limit;
     L.force_cmp = (sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     HIPCHK(agatha::launch_exotic(L, st));
     L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;

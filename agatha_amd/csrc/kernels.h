@@ -22,7 +22,8 @@ struct AlignLaunch {
     int n;
     unsigned int* queue;
     uint8_t* exotic;               // per pair kind: 0 = plain, 1 = holds letters outside ACGTN (compare kernel),
-                                   // 2 = abandoned by the packed-int16 kernel (int32 profile kernel takes it)
+                                   // 2 = abandoned by the packed-int16 kernel (int32 profile kernel takes it),
+                                   // 3 = scores out of the kernels' range (no kernel takes it: AGATHA_AMD_BAD_RESULT)
     int ncand;                     // candidates for the kind-0 pairs, in launch order
     KernelChoice cand[4];
     int* choice;                   // device: index of the candidate that takes the kind-0 pairs
@@ -30,6 +31,7 @@ struct AlignLaunch {
     float* totals;                 // device: [0] sum of steps over the batch, [1] steps of the longest pair (sort_scan_kernel)
     unsigned int* kind_counts;     // device: [0] pairs of kind 1, [1] pairs of kind 2 (kernels with nothing to do return at once)
     int force_cmp;                 // 1 = scores do not fit the byte profile: compare path for every pair
+    long long score_limit;         // 2^(30-K): scores (and, with z-drop off, their negatives) must stay below it in the H << K keys
     int32_t *score, *qend, *tend;
     AlignParams p;
     int num_cus;

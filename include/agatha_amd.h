@@ -29,7 +29,10 @@ typedef struct agatha_amd_scores {
     int32_t mismatch;     /* -x (penalty, positive) */
     int32_t gap_open;     /* -q */
     int32_t gap_extend;   /* -r */
-    int32_t slice_width;  /* -s: only decides WHEN z-drop is tested (reference semantics); any value >= 1 */
+    int32_t slice_width;  /* -s: only decides WHEN z-drop is tested (reference semantics); any value >= 1 is computed with an exact
+                             ring of anti-diagonal maxima.  The REFERENCE is only defined for s + 1 a power of two (1, 3, 7 ...):
+                             its ring index is `& (8 (s + 1) - 1)` (agatha_kernel.h:29,83,295) and aliases slots otherwise, so
+                             parity with it is claimed, and tested, for those values only */
     int32_t z_threshold;  /* -z: < 0 disables z-drop */
     int32_t band_width;   /* -w */
 } agatha_amd_scores;
@@ -40,7 +43,9 @@ enum {
     AGATHA_AMD_EBAND = -2,       /* band wider than the largest compiled window (agatha_amd_max_band()) */
     AGATHA_AMD_EWORKSPACE = -3,  /* workspace too small, see agatha_amd_workspace_bytes() */
     AGATHA_AMD_EHIP = -4,        /* HIP runtime error, text in agatha_amd_last_error() */
-    AGATHA_AMD_ERANGE = -5       /* match * min(max lengths) does not fit the kernel's 2^(30-K) score range (K = 8..13 by band) */
+    AGATHA_AMD_ERANGE = -5       /* match * min(max lengths) -- or, with z-drop off, mismatch * max(max lengths) -- does not fit the
+                                    kernel's 2^(30-K) score range (K = 8..13 by band); without length hints the pairs that do not
+                                    fit get AGATHA_AMD_BAD_RESULT instead */
 };
 
 const char* agatha_amd_strerror(int code);
@@ -76,8 +81,10 @@ int agatha_amd_pack_host(const uint8_t* h_unpacked, size_t nbytes, uint32_t* h_p
 int agatha_amd_seq_ops(void* stream, const uint8_t* d_unpacked, uint32_t* d_packed, const uint32_t* d_lens,
                        const uint32_t* d_offsets, const uint8_t* d_ops, uint32_t n_seqs);
 
-/* Result triple written for a pair whose true lengths exceed the max_*_len hints badly enough that the chosen lane
- * group cannot hold its band: (AGATHA_AMD_BAD_RESULT, -1, -1).  Correct hints (or 0 = unknown) never produce it. */
+/* Result triple (AGATHA_AMD_BAD_RESULT, -1, -1): written for a pair whose true lengths exceed the max_*_len hints badly
+ * enough that the chosen lane group cannot hold its band (correct hints, or 0 = unknown, never produce that), and, when no
+ * hints were given, for a pair so long that its scores could leave the kernels' 2^(30-K) range (hundreds of kilobases at
+ * wide bands; with hints such a call is refused with AGATHA_AMD_ERANGE). */
 #define AGATHA_AMD_BAD_RESULT INT32_MIN
 
 /* Sort + align one batch.  Replaces agatha_kernel_launcher (gasal_align.cu:10-23): the agatha_sort kernel,

@@ -105,6 +105,27 @@ def test_rejects_bad_arguments(eng):
         eng.align_host_batch(qb[:4], qb, qo, qo, ql, ql, _scores({}))                 # bytes not a multiple of 8
 
 
+def test_score_range_guard(eng):
+    """Scores travel as H << K in 32-bit keys (K = 10 at band 751): a pair that could exceed 2^(30-K) is refused -- the whole
+    call with AGATHA_AMD_ERANGE when the length hints prove it, that pair alone (AGATHA_AMD_BAD_RESULT, -1, -1) when the caller
+    gave no hints; the other pairs of the batch are aligned as usual.  Also on the negative side when z-drop is off."""
+    import agatha_amd
+    rng = np.random.default_rng(1)
+    long_ = synth.random_seq(rng, 12000).tobytes()
+    short = synth.random_seq(rng, 900).tobytes()
+    qs, ts = [long_, short], [long_, short]
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    for p in (dict(m=100, x=4, q=4, r=2, s=3, z=400, w=751),          # 12 000 x 100 > 2^20
+              dict(m=2, x=100, q=4, r=2, s=3, z=-1, w=751)):          # z-drop off: -100 per mismatch can run away as well
+        with pytest.raises(agatha_amd.AgathaError, match="range"):
+            eng.align_host_batch(qb, tb, qo, to, ql, tl, _scores(p))
+        s, q, t = eng.align_host_batch(qb, tb, qo, to, ql, tl, _scores(p), use_len_hint=False)
+        assert (int(s[0]), int(q[0]), int(t[0])) == (-2 ** 31, -1, -1)
+        exp = O.align_pairs([short], [short], O.make_params(**p), wide=True)
+        assert (int(s[1]), int(q[1]), int(t[1])) == tuple(int(v[0]) for v in exp)
+
+
 def _transform(seq, op):
     comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
     s = seq[::-1] if op & 1 else seq
