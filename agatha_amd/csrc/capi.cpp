@@ -37,7 +37,7 @@ DebugOption g_opts[] = {
     {"mig_timeout_us", "AGATHA_AMD_MIG_TIMEOUT_US", {50000}},   // wait for a suspended pair this long, then take it over
     {"mig_test_delay_us", "AGATHA_AMD_MIG_TEST_DELAY_US", {0}}, // tests: odd lane groups start this late
     {"prio_slice", "AGATHA_AMD_PRIO_SLICE", {-1}},     // > 0: SIMD partners alternate issue priority every 2^n ticks (10 ns each); -1: 2^15 on a static schedule, off otherwise; 0: off
-    {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {8}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured
+    {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts)
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
 };
 enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_COUNT };
@@ -73,7 +73,7 @@ constexpr uint32_t kMigMinPairs = 4096;
 size_t base_workspace_bytes(uint32_t n)
 {
     return round_up(sizeof(uint32_t) * (size_t)n) + round_up(sizeof(uint32_t) * kBuckets) + kAlign +
-           round_up(sizeof(agatha::AlignLaunch)) + round_up((size_t)n);
+           round_up(sizeof(agatha::AlignLaunch)) + round_up((size_t)n) + round_up(sizeof(int) * agatha::kSimdStepsInts);
 }
 size_t mig_workspace_bytes(uint32_t n)
 {
@@ -210,6 +210,7 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     unsigned int* queue = (unsigned int*)ws;     ws += kAlign;
     agatha::AlignLaunch* rec = (agatha::AlignLaunch*)ws;   ws += round_up(sizeof(agatha::AlignLaunch));
     uint8_t* exotic = (uint8_t*)ws;                          ws += round_up((size_t)n_alns);
+    int* simd_steps = (int*)ws;                              ws += round_up(sizeof(int) * agatha::kSimdStepsInts);
     // areas of the preemptive schedule, present when the caller sized the workspace for a batch this large
     const bool mig = n_alns > kMigMinPairs && workspace_bytes >= base_workspace_bytes(n_alns) + mig_workspace_bytes(n_alns) &&
                      !opt(OPT_NO_MIGRATE);
@@ -239,6 +240,8 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;
     L.mig_slot_dwords = 0;
     L.timeline = nullptr;
+    L.simd_steps = simd_steps;
+    HIPCHK(hipMemsetAsync(simd_steps, 0, sizeof(int) * agatha::kSimdStepsInts, st));
     L.prio_slice_bits = opt(OPT_PRIO_SLICE);
     L.prio_duty = opt(OPT_PRIO_DUTY);
     if (opt(OPT_TIMELINE) && workspace_bytes >= base_workspace_bytes(n_alns) + mig_workspace_bytes(n_alns)) {

@@ -49,6 +49,7 @@ struct AlignLaunch {
     unsigned int mig_timeout_ticks;  // 100 MHz ticks a group waits for a pair to be suspended before it takes the pair over
     uint32_t* timeline;            // device (debug option "timeline"): per wave of the int16 kernel {start, end (100 MHz ticks), HW_ID, XCC_ID, steps, pairs}
     int prio_slice_bits;           // > 0: the two waves of a SIMD take turns at high issue priority, in slices of 2^bits ticks of the 100 MHz clock
+    int* simd_steps;               // device: [2 workgroups][CU][SIMD] step counts the waves of a dealt single round tell each other
     int prio_duty;                 // of every 16 slices, the wave in slot 0 of its SIMD is the favoured one in this many
     unsigned int mig_test_delay_ticks;   // tests: odd lane groups sleep this long before they start (forces the take-over)
 };
@@ -61,6 +62,7 @@ constexpr int mig_fields(int P) { return P * 26 + 7 + ((2 * P + 1) * 9 + 1) / 2 
 // largest `spread` (how far below an anti-diagonal maximum an in-band cell can be) the packed-int16 kernel is offered for
 constexpr int kAlign16MaxSpread = 16000;
 constexpr int kMigMaxSlots = 16384;
+constexpr int kSimdStepsInts = 2 * 4 * 1024;          // (up to 1024 CUs)
 constexpr int kTimelineWaves = 4096, kTimelineDwords = 8;
 constexpr size_t kMigBufBytes = (size_t)68 << 20;
 

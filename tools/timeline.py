@@ -11,7 +11,7 @@ qb, qo, ql = workload.make_batch(qs); tb, to, tl = workload.make_batch(ts)
 b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); eng.synchronize()
 sc = agatha_amd.Scores.make()
 agatha_amd.set_debug_option("timeline", 1)
-modes = [(0, -1, 8), (0, -1, 8)]
+modes = [(0, -1, 0), (0, -1, 8), (0, 0, 8)]
 for nomig, pb, duty in modes:
     agatha_amd.set_debug_option("no_migrate", nomig)
     agatha_amd.set_debug_option("prio_slice", pb)
@@ -25,13 +25,33 @@ for nomig, pb, duty in modes:
     st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0          # microseconds
     hw = t[:, 2]; simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; se = (hw >> 13) & 3; xcc = t[:, 3] & 15
     wid = hw & 15
+    key = xcc * 1000000 + se * 10000 + cu * 100 + simd
+    cukey = xcc * 10000 + se * 100 + cu
     print(f"prio_slice={pb} wave slot ids:", dict(zip(*np.unique(wid, return_counts=True))), "fast waves by slot parity:", [float(np.round(np.median(((t[:, 1] - t[:, 0]) / 100.0 / np.maximum(t[:, 4], 1))[(wid & 1) == q]), 2)) for q in (0, 1)], "by workgroup half:", [float(np.round(np.median(((t[:, 1] - t[:, 0]) / 100.0 / np.maximum(t[:, 4], 1))[(np.arange(len(t)) // 4 >= len(t) // 8) == q]), 2)) for q in (False, True)])
+    nw = len(t)
+    same = sum(int(key[j] == key[j + nw // 2]) for j in range(nw // 2)) if nw % 8 == 0 else -1
+    print("  waves (b, w) and (b + half, w) on the same SIMD:", same, "of", nw // 2)
+    bywave = {}
+    for j in range(nw):
+        bywave.setdefault(int(key[j]), []).append(j)
+    rel = {}
+    for kk_, js in bywave.items():
+        if len(js) == 2:
+            a_, b_ = sorted(js)
+            r_ = ((b_ // 4) - (a_ // 4), (a_ % 4), (b_ % 4))
+            rel[r_] = rel.get(r_, 0) + 1
+    print("  SIMD partners (block distance, wave of first, wave of second) -> count:", sorted(rel.items(), key=lambda x: -x[1])[:12])
+    cus = {}
+    for j in range(nw):
+        cus.setdefault(int(cukey[j]), set()).add(j // 4)
+    print("  workgroups per CU:", sorted(set(tuple(sorted(v)) for v in list(cus.values())[:6])), "block distance of the two workgroups of a CU:", sorted(set(max(v) - min(v) for v in cus.values() if len(v) == 2))[:10])
     print(f"no_migrate={nomig} align={ms:.2f} ms waves={len(t)} schedule={b.schedule_info()}")
     print("  start us: min %.0f max %.0f   end us: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f" % (st.min(), st.max(), en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max()))
     print("  mean life %.0f us = %.1f%% of the kernel; steps per wave: min %d median %d max %d; pairs per wave (x4 groups): %d..%d" % ((en - st).mean(), 100 * (en - st).mean() / en.max(), t[:, 4].min(), np.median(t[:, 4]), t[:, 4].max(), t[:, 5].min(), t[:, 5].max()))
     us_per_step = (en - st) / np.maximum(t[:, 4], 1)
     print("  us per step: min %.2f p10 %.2f median %.2f p90 %.2f max %.2f" % (us_per_step.min(), np.percentile(us_per_step, 10), np.median(us_per_step), np.percentile(us_per_step, 90), us_per_step.max()))
     key = xcc * 1000000 + se * 10000 + cu * 100 + simd
+    cukey = xcc * 10000 + se * 100 + cu
     uniq, cnt = np.unique(key, return_counts=True)
     print("  distinct (xcc,se,cu,simd):", len(uniq), "waves per SIMD histogram:", dict(zip(*np.unique(cnt, return_counts=True))))
     cukey = xcc * 10000 + se * 100 + cu
