@@ -793,7 +793,7 @@ schedule_kernel(AlignLaunch L, int GS)
     __shared__ uint32_t pmaxs[1024];
     __shared__ uint32_t nzs[1024];
     const int n = L.n, m = L.mig_slots, t = threadIdx.x;
-    if (!L.mig_enabled || m <= 0 || n <= m || (long long)n > 8ll * m) { if (t == 0) L.sched[0] = 0; return; }
+    if (!L.mig_enabled || m <= 0 || n <= m || ((long long)n > 16ll * m && L.mig_enabled != 2)) { if (t == 0) L.sched[0] = 0; return; }
     const int W = (L.p.band_width + 7) >> 3, sw = L.p.slice_width;
     const int chunk = (n + 1023) / 1024;
     const int j0 = t * chunk, j1 = min(n, j0 + chunk);
@@ -818,12 +818,12 @@ schedule_kernel(AlignLaunch L, int GS)
         long long T = (P + m - 1) / m; if (T < (long long)pm) T = pm; if (T < 1) T = 1;
         L.cum[n] = (uint32_t)acc;
         // When is the static schedule the better one (measured): always up to ~2 rounds of pairs (the work queue
-        // then ends in a long tail on a few waves); up to 8 rounds when the pairs are long against the band -- the four lane
+        // then ends in a long tail on a few waves); up to 16 rounds when the pairs are long against the band -- the four lane
         // groups of a wave then start their pairs at different times, and every pair start is ~W steps on slower code paths,
-        // which short pairs (a bundled-dataset-like batch: 750 steps each) pay for more than they gain; beyond 8 rounds the
-        // queue balances by itself and also follows pairs that z-drop early.
+        // which short pairs (a bundled-dataset-like batch: 750 steps each) pay for more than they gain (24.7 against 21.1 ms);
+        // beyond that the queue balances by itself (70 000 pairs: 223.7 against 227.2 ms) and also follows pairs that z-drop early.
         const long long pavg = npairs ? P / (long long)npairs : 0;
-        const bool use = pm > 0 && P < (1ll << 30) && (10ll * n <= 22ll * m || pavg >= 12ll * (W + 1));
+        const bool use = pm > 0 && P < (1ll << 30) && (L.mig_enabled == 2 || 10ll * n <= 22ll * m || pavg >= 12ll * (W + 1));
         L.sched[0] = use ? 1 : 0; L.sched[1] = (int)T; L.sched[2] = (int)((P + T - 1) / T);
     }
     __syncthreads();

@@ -33,7 +33,7 @@ DebugOption g_opts[] = {
     {"no_int16", "AGATHA_AMD_NO_INT16", {0}},          // 1: the packed-int16 kernel is not a candidate
     {"force_int16", "AGATHA_AMD_FORCE_INT16", {0}},    // 1: ... is the only candidate (when the scores allow it)
     {"force_choice", "AGATHA_AMD_FORCE_CHOICE", {-1}}, // >= 0: candidate index that takes the plain pairs
-    {"no_migrate", "AGATHA_AMD_NO_MIGRATE", {0}},      // 1: pairs never move between lane groups (no preemptive schedule)
+    {"no_migrate", "AGATHA_AMD_NO_MIGRATE", {0}},      // 1: pairs never move between lane groups (no preemptive schedule); -1: always when possible
     {"mig_timeout_us", "AGATHA_AMD_MIG_TIMEOUT_US", {50000}},   // wait for a suspended pair this long, then take it over
     {"mig_test_delay_us", "AGATHA_AMD_MIG_TEST_DELAY_US", {0}}, // tests: odd lane groups start this late
     {"prio_slice", "AGATHA_AMD_PRIO_SLICE", {-1}},     // > 0: SIMD partners alternate issue priority every 2^n ticks (10 ns each); -1: 2^15 on a static schedule, off otherwise; 0: off
@@ -213,7 +213,7 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     int* simd_steps = (int*)ws;                              ws += round_up(sizeof(int) * agatha::kSimdStepsInts);
     // areas of the preemptive schedule, present when the caller sized the workspace for a batch this large
     const bool mig = n_alns > kMigMinPairs && workspace_bytes >= base_workspace_bytes(n_alns) + mig_workspace_bytes(n_alns) &&
-                     !opt(OPT_NO_MIGRATE);
+                     opt(OPT_NO_MIGRATE) <= 0;
     uint32_t* cum = (uint32_t*)ws;                           ws += round_up(sizeof(uint32_t) * ((size_t)n_alns + 1));
     int* mig_state = (int*)ws;                               ws += round_up(sizeof(int) * (agatha::kMigMaxSlots + 1));
     uint32_t* timeline = (uint32_t*)ws;                      ws += round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords);
@@ -262,7 +262,7 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     if (mig && L.ncand > 0 && L.cand[0].kind == 1 && L.cand[0].G < 64) {
         const int slots = L.cand[0].capacity, dwords = agatha::align16_mig_fields(L.cand[0].S / 2) * L.cand[0].G;
         if (slots <= agatha::kMigMaxSlots && (size_t)slots * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes) {
-            L.mig_enabled = 1; L.mig_slots = slots; L.mig_slot_dwords = dwords;
+            L.mig_enabled = opt(OPT_NO_MIGRATE) < 0 ? 2 : 1; L.mig_slots = slots; L.mig_slot_dwords = dwords;
             HIPCHK(hipMemsetAsync(mig_state, 0, sizeof(int) * ((size_t)slots + 1), st));
             HIPCHK(agatha::launch_schedule(L, st));
         }

@@ -39,7 +39,7 @@ struct AlignLaunch {
     int no_deal;                   // 1 = every pair from the queue, no dealt first round (AGATHA_AMD_NO_DEAL, A/B runs)
     const AlignLaunch* self_dev;   // device copy of this record (lives in the workspace)
     // ---- preemptive static schedule of the packed-int16 throughput shape (pairs migrate between lane groups) ----
-    int mig_enabled;               // workspace holds the areas below and the option is on
+    int mig_enabled;               // workspace holds the areas below and the option is on (2: use the schedule whenever it is possible: A/B runs)
     int mig_slots;                 // lane groups of the full persistent grid of candidate 0 (its capacity)
     uint32_t* cum;                 // device: [n + 1] exclusive prefix sums of the pairs' step counts in sorted order
     int* sched;                    // device: [0] 1 = static schedule in force, [1] T = steps per lane group, [2] groups used
