@@ -886,12 +886,14 @@ hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool fo
     if (have16) {
         KernelChoice k;
         k.kind = 1; k.G = G16; k.S = 2 * P16;
-        k.t_lat = 1.75f * P16 + 1.75f; k.t_load = 4.45f * P16;
+        // (microseconds per step, round 2: a lone wave 7.2 / 6.7 / 3.6 for P = 3 / 2 / 1; two waves per SIMD taking turns at
+        //  the issue priority 10.3 / 7.8 / ~5)
+        k.t_lat = 1.8f * P16 + 1.8f; k.t_load = 2.55f * P16 + 2.6f;
         k.capacity = L.num_cus * 8 * (64 / G16);
         L.cand[L.ncand++] = k;
         if (GL16 && !force16) {
             k.G = GL16; k.S = 2 * PL16;
-            k.t_lat = 1.75f * PL16 + 1.75f; k.t_load = 4.45f * PL16;
+            k.t_lat = 1.8f * PL16 + 1.8f; k.t_load = 2.55f * PL16 + 2.6f;
             k.capacity = L.num_cus * 8 * (64 / GL16);
             L.cand[L.ncand++] = k;
         }

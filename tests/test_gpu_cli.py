@@ -200,3 +200,20 @@ def test_cli_start_positions(tmp_path):
     exp = np.stack([es, eq, et, xq, xt], axis=1)
     match_batches(got, [exp[k:k + 50] for k in range(0, 120, 50)])
     assert (exp[:, 3] > 0).sum() > 30
+
+
+def test_cli_batch_larger_than_one_round_of_lane_groups(tmp_path):
+    """`manual -a 12000` on 11 000 short pairs at a narrow band: one GASAL batch holds more pairs than the int16 kernel has
+    lane groups (8192), so the C++ layer's workspace carries the areas of the preemptive schedule and pairs are suspended
+    and resumed across lane groups behind gasal_aln_async -- same score lines as the oracle, also with start positions."""
+    qs, ts = synth.make_pairs(21, 11000, lambda r: int(r.integers(60, 700)), 0.03, 0.03, 0.04)
+    f1, f2, raw = tmp_path / "a.fa", tmp_path / "b.fa", tmp_path / "raw.log"
+    write_fasta(f1, qs, header=">", width=10 ** 9)
+    write_fasta(f2, ts, header=">", width=10 ** 9)
+    P = O.make_params(w=24, z=100)
+    es, eq, et = O.align_pairs(qs, ts, P, wide=True, threads=8)
+    r = subprocess.run([MANUAL, "-p", "-w", "24", "-z", "100", "-a", "12000", str(f1), str(f2), str(raw)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (parse(r.stdout) == np.stack([es, eq, et], axis=1)).all()
+    assert len(open(raw).read().split()) == 1
