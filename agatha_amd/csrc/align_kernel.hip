@@ -787,7 +787,7 @@ hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st)
 // step counts (0 for pairs the int16 kernel skips), their prefix sums and T, and decides whether the schedule is used.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-schedule_kernel(AlignLaunch L, int GS)
+schedule_kernel(AlignLaunch L, int GS, int G)
 {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t pmaxs[1024];
@@ -804,7 +804,8 @@ schedule_kernel(AlignLaunch L, int GS)
         const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
         if (Q <= 0 || R <= 0 || min(W + 1, min(pql, prl)) > GS || pql + GS >= 32760 || prl + GS >= 32760) return 1u;
         const int total = pql + prl - 1;
-        return (uint32_t)(((total + sw - 1) / sw) * sw + 2);  // dry step + whole slices + the final check step
+        // dry step + whole slices + the final check step + what starting it costs (every start stalls all 64 / G groups of the wave)
+        return (uint32_t)(((total + sw - 1) / sw) * sw + 2 + kMigPairOverheadSteps * (64 / G));
     };
     uint32_t sum = 0, mx = 0, nz = 0;
     for (int j = j0; j < j1; j++) { const uint32_t p = steps_of(j); sum += p; mx = max(mx, p); nz += p > 1u; }
@@ -835,7 +836,7 @@ hipError_t launch_schedule(const AlignLaunch& L, hipStream_t st)
 {
     if (!L.mig_enabled) return hipSuccess;
     const KernelChoice& k = L.cand[0];
-    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, st, L, k.G * k.S);
+    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, st, L, k.G * k.S, k.G);
     return hipGetLastError();
 }
 

@@ -61,6 +61,11 @@ enum { MIG_FRESH = 0, MIG_RUNNING = 1, MIG_SAVED = 2, MIG_DONE = 3, MIG_STOLEN =
 constexpr int mig_fields(int P) { return P * 26 + 7 + ((2 * P + 1) * 9 + 1) / 2 + 10; }
 // largest `spread` (how far below an anti-diagonal maximum an in-band cell can be) the packed-int16 kernel is offered for
 constexpr int kAlign16MaxSpread = 16000;
+// what a pair costs its lane group beyond its own steps (finding it, loading its lengths and reference words, building the
+// score profiles: ~4 dependent memory round trips), in steps, per lane group of the wave -- every start stalls all the
+// groups of its wave, so a pair costs its group kMigPairOverheadSteps * (64 / G) steps; the schedule counts that, so that
+// lane groups holding many tiny pairs are not the last to finish
+constexpr int kMigPairOverheadSteps = 4;
 constexpr int kMigMaxSlots = 16384;
 constexpr int kSimdStepsInts = 2 * 4 * 1024;          // (up to 1024 CUs)
 constexpr int kTimelineWaves = 4096, kTimelineDwords = 8;

@@ -12,6 +12,9 @@ def step_count(Q, R, sw):
     return -(-total // sw) * sw + 2
 
 
+PAIR_OVERHEAD = 16         # kMigPairOverheadSteps * (64 / G): what starting a pair costs its lane group, in steps (counted by the schedule)
+
+
 def schedule(p, m):
     """p: step counts in sorted order (0 = a pair this kernel skips).  Returns T and, per lane group, its list of segments
     (pair, first step, last step + 1, kind) in the order the group runs them: kind 'early' = first part of the pair that
@@ -45,7 +48,7 @@ def test_every_step_of_every_pair_runs_exactly_once_and_in_order(seed):
     n = int(rng.integers(m + 1, 6 * m))
     sw = int(rng.choice([1, 3, 7]))
     Q = rng.integers(1, 3000, n); R = rng.integers(1, 3000, n)
-    p = np.array([step_count(int(q), int(r), sw) for q, r in zip(Q, R)])
+    p = np.array([step_count(int(q), int(r), sw) + PAIR_OVERHEAD for q, r in zip(Q, R)])
     p[rng.random(n) < 0.05] = 0                                     # pairs of another kind: skipped
     p = -np.sort(-p)                                                # longest first
     T, groups = schedule(p, m)

@@ -5,13 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import agatha_amd
 from agatha_amd import workload
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+cfgname = sys.argv[2] if len(sys.argv) > 2 else "cfg_c1"
 eng = agatha_amd.Engine(0)
-qs, ts = workload.cfg_c1(n=n)
+qs, ts = getattr(workload, cfgname)(n=n)
 qb, qo, ql = workload.make_batch(qs); tb, to, tl = workload.make_batch(ts)
 b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); eng.synchronize()
 sc = agatha_amd.Scores.make()
 agatha_amd.set_debug_option("timeline", 1)
-modes = [(0, -1, 0), (0, -1, 8), (0, 0, 8)]
+modes = [(-1, -1, 0), (1, -1, 0), (-1, 0, 0)] if cfgname != 'cfg_c1' else [(0, -1, 0), (0, -1, 8), (0, 0, 8)]
 for nomig, pb, duty in modes:
     agatha_amd.set_debug_option("no_migrate", nomig)
     agatha_amd.set_debug_option("prio_slice", pb)
