@@ -20,7 +20,7 @@ hipError_t align16_entry_7(const AlignLaunch&, int, int, int, hipStream_t);
 
 struct Cfg16 { int G, P; };
 static const Cfg16 kCfgs16[] = {       // ascending G * 2P: windows of 32, 64, 96, 128, 192 blocks; then the latency shapes
-    {16, 1}, {16, 2}, {16, 3}, {32, 2}, {32, 3}, {64, 1}, {64, 2},
+    {16, 1}, {16, 2}, {16, 3}, {32, 2}, {32, 3}, {64, 1}, {64, 2}, {128, 1},
 };
 
 int align16_mig_fields(int P) { return mig_fields(P); }
@@ -52,6 +52,8 @@ bool align16_config(const AlignParams& p, int window_blocks, int* G, int* P, int
     *GL = 0; *PL = 0;
     for (const Cfg16& l : kCfgs16)            // latency shape: 64 lanes per pair, fewer register pairs per lane
         if (l.G == 64 && l.G * 2 * l.P >= window_blocks && l.P < c->P) { *GL = l.G; *PL = l.P; break; }
+    // ... or one pair on two cooperating waves when that halves the register pairs per lane again (windows of 129..256 blocks)
+    if (*GL == 64 && *PL == 2 && window_blocks <= 256) { *GL = 128; *PL = 1; }
     return true;
 }
 

@@ -894,8 +894,8 @@ hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool fo
         L.cand[L.ncand++] = k;
         if (GL16 && !force16) {
             k.G = GL16; k.S = 2 * PL16;
-            k.t_lat = 1.8f * PL16 + 1.8f; k.t_load = 2.55f * PL16 + 2.6f;
-            k.capacity = L.num_cus * 8 * (64 / GL16);
+            k.t_lat = 1.8f * PL16 + 1.8f + (GL16 == 128 ? 0.4f : 0.f); k.t_load = 2.55f * PL16 + 2.6f;
+            k.capacity = GL16 == 128 ? L.num_cus * 4 : L.num_cus * 8 * (64 / GL16);
             L.cand[L.ncand++] = k;
         }
     }

@@ -390,3 +390,34 @@ def test_migration_take_over_when_the_first_part_never_comes(eng):
         assert _same(got, exp)
     finally:
         agatha_amd.set_debug_option("force_choice", -1)
+
+
+def test_one_pair_on_two_cooperating_waves(eng):
+    """Latency shape for windows of 129..256 blocks (bands 1017..2040 on long pairs, e.g. BASELINE's ultra-long config): one
+    pair on the two waves of a 128-thread workgroup, <128, 1> -- the H hand-off of lane 63, the step's reduced maxima and
+    the queue position cross the wave boundary through LDS, one barrier per step.  Bit-exact against the oracle for several
+    bands / cut diagonals, with z-drop, ragged ends, and more pairs than workgroups fit (queue)."""
+    rng = np.random.default_rng(31)
+    qs, ts = [], []
+    for k in range(40):
+        ref = WL.random_seq(rng, int(rng.integers(9000, 16000)))
+        rd = WL.mutate(rng, ref, 0.03, 0.03, 0.04)
+        if k % 5 == 0:
+            rd = np.concatenate([rd[:rd.size // 2], WL.random_seq(rng, rd.size // 2)])          # breaks: z-drop
+        qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    for p in (dict(BASE, w=1500), dict(BASE, w=1024, z=100), dict(m=1, x=4, q=6, r=2, s=1, z=400, w=1221)):
+        qb, qo, ql = WL.make_batch(qs)
+        tb, to, tl = WL.make_batch(ts)
+        exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=8)
+        agatha_amd.set_debug_option("force_int16", 0)
+        try:
+            b = eng.batch(qb, tb, qo, to, ql, tl)
+            try:
+                b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
+                got = [b.res_host[j].copy() for j in range(3)]
+                assert b.kernel_choice() == ("int16", 128, 2)
+            finally:
+                b.free()
+        finally:
+            agatha_amd.set_debug_option("force_int16", 1)
+        assert _same(got, exp)
