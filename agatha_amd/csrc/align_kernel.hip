@@ -29,420 +29,7 @@
 
 namespace agatha {
 
-// initial column state of column block r: H(-1, c), F(0, c)  (agatha_kernel.h:133-148, 207-215)
-__device__ __forceinline__ void init_col(int r, int R, int w, int gapoe, int ge, int neg, int (&h)[8], int (&f)[8], int& corner)
-{
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-        const int c = 8 * r + m;
-        const int k = -(gapoe + ge * c);
-        const bool in = (c < R) && (c <= w);
-        h[m] = in ? k : neg;
-        f[m] = in ? k - gapoe : neg;
-    }
-    const int kc = -(gapoe + ge * (8 * r - 1));
-    corner = (r == 0) ? 0 : ((8 * r - 1) <= w ? kc : neg);
-}
-
-// One 8x8 block (q, r): the reference's CORE_COMPUTE / CORE_COMPUTE_BOUNDARY sweep
-// (agatha_kernel.h:20-46, 230-269) on register state.
-//   h, f    column state H(row above, c), F(next row, c) of the 8 columns       (in/out)
-//   corner  H(row above, column left of the block)                             (in/out)
-//   rh      H(row, column left of the block) for the 8 rows                    (in)
-//   e       E(row, first column) in, E(row, column right of the block) out     (in/out)
-//   oh      H(row, last column) out
-// Substitution scores come from a per-(lane, slot) PROFILE in LDS: for the 8 reference bases of this column block,
-// one row of 8 signed bytes per query-base class (A, C, G, T, N), built once when the column block starts.  A row of
-// the block then costs one ds_read_b64 and each cell's "score + diagonal" is a single v_add_u32_sdwa (sign-extended
-// byte operand) instead of compare + select + add.  Pairs that contain letters outside ACGTN (flagged by
-// exotic_kernel) take the compare path (use_cmp, wave-uniform), which also carries the N rule of
-// gasal_kernels.h:48-50.
-// MASKED: per-cell band test of boundary blocks and the row limit of the last row block, as EXEC masks
-//         built once per block (km: one lane mask per cell diagonal jl-il).
-template <bool MASKED, bool CMP, int K>
-__device__ __forceinline__ void block8x8(int (&h)[8], int (&f)[8], int& corner, const int (&rh)[8], int (&e)[8],
-                                         int (&oh)[8], int (&A)[15], uint32_t qword, uint32_t rword,
-                                         const uint2* __restrict__ prof, int va, int vnb, int gapoe, int ge,
-                                         int crel0, int nrows, int tu, int tl, int t0)
-{
-    // all eight profile rows are requested up front: their LDS latency then hides behind the mask set-up and the
-    // first rows instead of stalling every row (class of a query base = bits 3..1 of its code:
-    // A(1)->0 C(3)->1 T(4)->2 G(7)->3 N(14)->7)
-    uint2 pw[8];
-    if (!CMP) {
-#pragma unroll
-        for (int il = 0; il < 4; il++) pw[il] = prof[((qword >> (29 - 4 * il)) & 7u) * 64u];
-    }
-    int cj[8];
-#pragma unroll
-    for (int jl = 0; jl < 8; jl++) cj[jl] = crel0 + jl;
-    unsigned long long km[15];
-    if (MASKED) {
-        // Away from the matrix corners an edge block has tu == t0 (upper edge) or tl == t0 (lower edge), t0 = w - 8W,
-        // and every other block has no skipped cell: then the 15 lane masks are two ballots combined with
-        // wave-uniform predicates in SALU.  Anything else (clamped corners, bands narrower than a block) takes the
-        // general per-lane compares.
-        const bool up = (tu == t0) && (tl >= 7), lo = (tl == t0) && (tu >= 7), none = (tu >= 7) && (tl >= 7);
-        if (__builtin_expect(__all(up || lo || none), 1)) {
-            const unsigned long long mu = __builtin_amdgcn_ballot_w64(up), ml = __builtin_amdgcn_ballot_w64(lo);
-#pragma unroll
-            for (int kk = 0; kk < 15; kk++)
-                km[kk] = ~(((kk - 7) > t0 ? mu : 0ull) | ((7 - kk) > t0 ? ml : 0ull));
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 15; kk++)     // tu, tl >= -7 always, so kk = 0 never fails the first test and kk = 14 never the second
-                km[kk] = (kk == 0 ? ~0ull : __builtin_amdgcn_ballot_w64((kk - 7) <= tu)) &
-                         (kk == 14 ? ~0ull : __builtin_amdgcn_ballot_w64((7 - kk) <= tl));
-        }
-    }
-#pragma unroll
-    for (int il = 0; il < 8; il++) {
-        if (!CMP && il == 1) {                  // second half of the profile rows: requested three rows ahead of use
-#pragma unroll
-            for (int i2 = 4; i2 < 8; i2++) pw[i2] = prof[((qword >> (29 - 4 * i2)) & 7u) * 64u];
-        }
-        if (!MASKED || il < nrows) {            // rows past the end of the query exist only in the last row block
-            int t[8];
-            if (CMP) {
-                const uint32_t qb = (qword >> (28 - 4 * il)) & 15u;
-#pragma unroll
-                for (int jl = 0; jl < 8; jl++) {
-                    const uint32_t rb = (rword >> (28 - 4 * jl)) & 15u;
-                    int sc = (qb == rb) ? va : vnb;
-                    sc = (qb == N_VALUE || rb == N_VALUE) ? -1 : sc;
-                    const int d = (jl == 0) ? ((il == 0) ? corner : rh[il - 1]) : h[jl - 1];
-                    t[jl] = sc + d;
-                }
-            } else {
-                const uint2 w = pw[il];
-#pragma unroll
-                for (int jl = 0; jl < 8; jl++) {
-                    const uint32_t word = (jl & 1) ? w.y : w.x;            // even columns in .x, odd in .y
-                    const int sc = (int)(int8_t)((word >> (8 * (3 - (jl >> 1)))) & 0xffu);
-                    const int d = (jl == 0) ? ((il == 0) ? corner : rh[il - 1]) : h[jl - 1];
-                    t[jl] = sc + d;
-                }
-            }
-            // every diagonal term is taken from the PREVIOUS row's H: pin them before H is overwritten
-#pragma unroll
-            for (int jl = 0; jl < 8; jl++) asm volatile("" : "+v"(t[jl]));
-            int ev = e[il];
-#pragma unroll
-            for (int jl = 0; jl < 8; jl++) {
-                if (!MASKED || __builtin_amdgcn_inverse_ballot_w64(km[jl - il + 7])) {
-                    const int hn = imax3(t[jl], f[jl], ev);
-                    const int tg = t[jl] - gapoe;
-                    f[jl] = imax(tg, f[jl] - ge);
-                    ev = imax(tg, ev - ge);
-                    h[jl] = hn;
-                    A[il + jl] = imax(A[il + jl], (int)(((uint32_t)hn << K) + (uint32_t)cj[jl]));
-                }
-            }
-            oh[il] = h[7]; e[il] = ev;
-        }
-    }
-    // p[1] = h[0] of the last processed row (agatha_kernel.h:28).  A block with fewer than 8 rows is the last
-    // block of its column (q == pql-1), after which the corner is never read again, so row 7 is always right.
-    corner = rh[7];
-}
-
-// Score profile of one column block: rows of 8 signed bytes (even columns in .x, odd in .y, column 0/1 in the top
-// byte) for the query-base classes 0..3 = A, C, T, G and 7 = N.  SWAR on the 8 packed reference codes.
-__device__ __forceinline__ void build_profile(uint2* __restrict__ prof, uint32_t rword, int a, int b)
-{
-    const uint32_t Re = (rword >> 4) & 0x0F0F0F0Fu, Ro = rword & 0x0F0F0F0Fu;  // columns 0,2,4,6 / 1,3,5,7
-    const uint32_t A4 = ((uint32_t)a & 0xFFu) * 0x01010101u, NB4 = ((uint32_t)(-b) & 0xFFu) * 0x01010101u;
-    const uint32_t BMe = NB4 | eq_bytes(Re, 0x0E0E0E0Eu), BMo = NB4 | eq_bytes(Ro, 0x0E0E0E0Eu);   // -b, or -1 where ref is N
-    const uint32_t codes[4] = {0x01010101u, 0x03030303u, 0x04040404u, 0x07070707u};              // A C T G
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const uint32_t me = eq_bytes(Re, codes[c]), mo = eq_bytes(Ro, codes[c]);
-        prof[c * 64] = make_uint2((A4 & me) | (BMe & ~me), (A4 & mo) | (BMo & ~mo));
-    }
-    prof[7 * 64] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);                                          // query N: always -1
-}
-
-template <int G, int S, bool CMP>
-__global__ void __launch_bounds__(256, (S <= 3 ? 2 : 1))
-align_kernel(const AlignLaunch* __restrict__ La, AlignParams P, int kid, int takes2)
-{
-    // kid: index of this kernel among the candidates for the plain (kind-0) pairs, chosen on the device (record_kernel);
-    // takes2: this launch also takes the pairs the int16 kernel handed over / could not take (kind 2)
-    if (!CMP && !takes2 && *La->choice != kid) return;
-    if (!CMP && takes2 && *La->choice != kid && La->kind_counts[1] == 0u) return;      // nothing was handed over
-    if (CMP && !La->force_cmp && La->kind_counts[0] == 0u) return;                      // no pair with other letters
-    // Batch pointers are read from the launch record only where a pair starts or ends: keeping a dozen 64-bit
-    // pointers live through the DP loop would push the band masks (30 SGPRs) into spills.
-    constexpr int GS = G * S;
-    constexpr int K = KeyBits<GS>::value;
-    constexpr int KMASK = (1 << K) - 1;
-    constexpr int NEGK = NEG_INF2;
-
-    __shared__ uint2 s_prof[4 * S * 8 * 64];      // [wave][slot][class][lane] score profiles (block8x8)
-    const int lane = threadIdx.x & 63;
-    uint2* const prof0 = s_prof + (threadIdx.x >> 6) * (S * 8 * 64) + lane;
-    const int k = lane & (G - 1);                 // lane inside the group
-    const int gbase = lane & ~(G - 1);            // first lane of the group
-    const int left_lane = gbase | ((k + G - 1) & (G - 1));
-
-    const int gapoe = P.gap_open + P.gap_extend, ge = P.gap_extend;
-    const int sw = P.slice_width, z = P.z_threshold, w = P.band_width;
-    const int W = (w + 7) >> 3;
-    int va = P.match, vnb = -P.mismatch;               // kept in VGPRs: both arms of the score select (compare path)
-
-    // ---- per-pair state (uniform inside a group) ----
-    int Q = 0, R = 0, pql = 0, prl = 0, total = 0, lim = 0, pair = 0;
-    // sequence words are read through explicit global (address space 1) pointers: a pointer loaded from the launch
-    // record is otherwise treated as generic and costs flat_load + a wait on both memory counters
-    typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
-    gptr_t pq = nullptr;
-    gptr_t pt = nullptr;
-    int i = 0, y = 0, ss = 0, se = 0, cb_prev = 0;
-    bool alive = false, exhausted = false, final_step = false;
-    int best = 0, best_t = 0, best_q = 0;
-
-    // ---- per-lane state ----
-    int rcur[S], corner[S];
-    int h[S][8], f[S][8];
-    uint32_t rword[S];
-    uint32_t qcur[S];                              // packed query word of the row block each slot works on this step
-    int xh[S + 1][8], xe[S + 1][8], xr[S + 1];   // hand-off: X[s] feeds slot s, X[S] leaves slot S-1
-    int A[15];
-
-#pragma unroll
-    for (int s = 0; s < S; s++) { rcur[s] = 0; corner[s] = 0; rword[s] = 0; qcur[s] = 0;
-#pragma unroll
-        for (int m = 0; m < 8; m++) { h[s][m] = 0; f[s][m] = 0; } }
-#pragma unroll
-    for (int s = 0; s <= S; s++) { xr[s] = -2;
-#pragma unroll
-        for (int m = 0; m < 8; m++) { xh[s][m] = 0; xe[s][m] = 0; } }
-#pragma unroll
-    for (int x = 0; x < 15; x++) A[x] = INT_MIN;
-
-    for (;;) {
-        // ------------------------------------------------------------------ work queue
-        const bool need = !alive && !exhausted;
-        if (__builtin_expect(__any(need), 0)) {
-            int idx = 0;
-            if (need && k == 0) idx = (int)atomicAdd(La->queue + (CMP ? 2 : takes2 ? 1 : 3), 1u);      // one queue head per launch
-            idx = lane_read(idx, gbase);
-            if (need) {
-                if (idx >= La->n) exhausted = true;
-                else {
-                    pair = (int)La->order[idx];
-                    // two launches share the work: this instantiation only takes the pairs of its kind (the profile
-                    // kernel skips pairs with letters outside ACGTN, the compare kernel takes exactly those)
-                    // pair kinds: 0 = plain letters (the chosen candidate kernel), 1 = letters outside ACGTN (compare
-                    // kernel), 2 = handed over by / withheld from the packed-int16 kernel (int32 profile kernel)
-                    const int kind = La->exotic[pair];
-                    const bool mine = CMP ? (La->force_cmp || kind == 1) : ((takes2 && kind == 2) || (kind == 0 && *La->choice == kid));
-                    if (mine) {
-                    Q = (int)La->qlens[pair]; R = (int)La->tlens[pair];
-                    pq = (gptr_t)(La->packed_q + (La->qoffs[pair] >> 3));
-                    pt = (gptr_t)(La->packed_t + (La->toffs[pair] >> 3));
-                    pql = (Q + 7) >> 3; prl = (R + 7) >> 3;
-                    total = prl + pql - 1; lim = Q + R - 1;
-                    best = 0; best_t = 0; best_q = 0;
-                    i = 0; y = 0; cb_prev = 0; final_step = false;
-                    ss = 0;
-                    se = imin(imin(prl - 1, sw - 1), (((sw - 1) * 8 + 7 + w) / 2) / 8);
-#pragma unroll
-                    for (int s = 0; s < S; s++) {
-                        rcur[s] = k * S + s;
-                        init_col(rcur[s], R, w, gapoe, ge, NEGK, h[s], f[s], corner[s]);
-                        rword[s] = (rcur[s] < prl) ? pt[rcur[s]] : 0xEEEEEEEEu;
-                        if (!CMP) build_profile(prof0 + s * (8 * 64), rword[s], P.match, P.mismatch);
-                        const int q0 = 0 - rcur[s];                      // row block of step 0 (only column block 0 has one)
-                        qcur[s] = (q0 >= 0 && q0 < pql) ? pq[q0] : 0u;
-                    }
-#pragma unroll
-                    for (int s = 0; s <= S; s++) xr[s] = -2;
-#pragma unroll
-                    for (int x = 0; x < 15; x++) A[x] = INT_MIN;
-                    alive = true;
-                    if (Q <= 0 || R <= 0) {           // nothing to align
-                        if (k == 0) { La->score[pair] = 0; La->qend[pair] = 0; La->tend[pair] = 0; }
-                        alive = false;
-                    } else if (imin(W + 1, imin(pql, prl)) > GS) {
-                        // the caller's length hint was too small for this pair: refuse loudly instead of aligning
-                        // with a window that does not hold the band (include/agatha_amd.h: AGATHA_AMD_BAD_RESULT)
-                        if (k == 0) { La->score[pair] = INT_MIN; La->qend[pair] = -1; La->tend[pair] = -1; }
-                        alive = false;
-                    }
-                    }
-                }
-            }
-        }
-        if (!__any(alive)) {
-            if (__all(exhausted)) break;
-            continue;                              // every group drew a pair of the other kind: draw again
-        }
-        // the steps run in an inner loop of their own, left only when a group wants a new pair (with the queue code in
-        // the same loop the register allocator spills)
-        do {
-
-        // ------------------------------------------------------------------ one step
-        // column base of the packed maxima: one block left of the lowest active column block
-        const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
-        {
-            const int delta = cb - cb_prev;       // 0 or 8; saturating so that the empty marker INT_MIN survives
-#pragma unroll
-            for (int x = 0; x < 7; x++) A[x] = __builtin_elementwise_sub_sat(A[x], delta);
-        }
-
-        // Which slots leave their column after this step is known now (used by the prefetch after the slot loop).
-        bool adv[S];
-        bool any_adv = false;
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            adv[s] = alive && (i + 1 - rcur[s] > imin(pql - 1, rcur[s] + W));
-            any_adv |= adv[s];
-        }
-
-#pragma unroll
-        for (int s = S - 1; s >= 0; s--) {
-            const int r = rcur[s], q = i - r;
-            const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
-            const bool active = alive && !final_step && r < prl && q >= cs && q <= ce && r >= ss && r <= se;
-            xr[s + 1] = active ? r : -2;
-            const uint32_t qword = qcur[s];
-            const uint32_t rw = rword[s];
-            const int nrows = imin(8, Q - 8 * q);
-            const bool boundary = (q == cs) || (q == ce);               // agatha_kernel.h:243
-            if (active) {
-                if (__builtin_expect(y == 0 && r == prl - 1, 0)) {   // pass start: padded ref columns fall back to -inf (agatha_kernel.h:207-215)
-#pragma unroll
-                    for (int m = 0; m < 8; m++) if (8 * r + m >= R) { h[s][m] = NEGK; f[s][m] = NEGK; }
-                }
-                const bool left_ok = (xr[s] == r - 1);
-                int rh[8];
-                if (__builtin_expect(__any(!left_ok && 8 * q <= w), 0)) {
-                    // a row block starts inside the first w rows: its left boundary holds real gap scores
-#pragma unroll
-                    for (int il = 0; il < 8; il++) {
-                        const int row = 8 * q + il;
-                        const int kk = -(gapoe + ge * row);
-                        const int ih = (row <= w) ? kk : NEGK;                // H(row, -1)   (agatha_kernel.h:126-131)
-                        const int ie = (row <= w) ? kk - gapoe : NEGK;        // E(row, 0)
-                        rh[il] = left_ok ? xh[s][il] : ih;
-                        xe[s + 1][il] = left_ok ? xe[s][il] : ie;             // E travels in place through the block
-                    }
-                } else {
-#pragma unroll
-                    for (int il = 0; il < 8; il++) {
-                        rh[il] = left_ok ? xh[s][il] : NEGK;
-                        xe[s + 1][il] = left_ok ? xe[s][il] : NEGK;
-                    }
-                }
-                const int tu = boundary ? w + 8 * q - 8 * r : 1000;     // cell skipped when jl - il > tu (:33)
-                const int tl = boundary ? w - 8 * q + 8 * r : 1000;     //                or il - jl > tl
-                const int crel0 = 8 * r - cb;
-                // Edge blocks (band test) exist on every anti-diagonal, so a mask-free variant would rarely run for
-                // a whole wave; Ns are rare (padding of the last column block, occasional N in a read).
-                block8x8<true, CMP, K>(h[s], f[s], corner[s], rh, xe[s + 1], xh[s + 1], A, qword, rw, prof0 + s * (8 * 64),
-                                       va, vnb, gapoe, ge, crel0, nrows, tu, tl, w - 8 * W);
-            }
-        }
-        // Prefetch for step i + 1, issued once per step: every block of this step is done, so the registers are free,
-        // and the reduce / z-drop tail below hides the latency (nothing else waits on vmcnt in between).
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            const int rn = adv[s] ? rcur[s] + GS : rcur[s];
-            const int qn = i + 1 - rn;
-            uint32_t qv = 0u;
-            if (alive && qn >= 0 && qn < pql) qv = pq[qn];
-            qcur[s] = qv;
-            if (adv[s]) rword[s] = (rn < prl) ? pt[rn] : 0xEEEEEEEEu;
-        }
-        // X[S] of the left neighbour lane becomes X[0]
-#pragma unroll
-        for (int il = 0; il < 8; il++) { xh[0][il] = lane_read(xh[S][il], left_lane); xe[0][il] = lane_read(xe[S][il], left_lane); }
-        xr[0] = lane_read(xr[S], left_lane);
-
-        // ------------------------------------------------------------------ anti-diagonals 8i..8i+7 are complete
-        bool stopped = false;
-        int vred[8];
-#pragma unroll
-        for (int x = 0; x < 8; x++) vred[x] = A[x];
-        group_max8<G>(vred, lane);
-        // Fast path (wave-uniform): every anti-diagonal of this step is non-empty, inside the pair, and within z of the
-        // running maximum, so z-drop cannot fire (agatha_kernel.h:304 needs best - H > z + l*ge >= z) and only the
-        // running maximum and its position have to be advanced.
-        bool calm = !final_step && (8 * i + 7 < lim);
-        {
-            int lo8 = vred[0];
-#pragma unroll
-            for (int x = 1; x < 8; x++) lo8 = imin(lo8, vred[x]);
-            int hi8 = vred[0];
-#pragma unroll
-            for (int x = 1; x < 8; x++) hi8 = imax(hi8, vred[x]);
-            calm = calm && lo8 != INT_MIN && (z < 0 || imax(best, hi8 >> K) - (lo8 >> K) <= z);
-        }
-        if (__builtin_expect(__all(calm || !alive), 1)) {
-#pragma unroll
-            for (int x = 0; x < 8; x++) {
-                const int H = vred[x] >> K;
-                if (alive && H > best) { best = H; best_t = (vred[x] & KMASK) + cb; best_q = 8 * i + x - best_t; }
-            }
-        } else {
-#pragma unroll
-            for (int x = 0; x < 8; x++) {
-                const int v = vred[x];
-                const int d = 8 * i + x;
-                const bool chk = alive && !stopped && (final_step || d < lim);       // agatha_kernel.h:293-294 / 337
-                int H = v >> K, c = (v & KMASK) + cb;
-                if (v == INT_MIN) { H = -32768; c = 0; }                              // empty anti-diagonal
-                if (chk) {                                                           // agatha_kernel.h:297-309
-                    if (H > best) { best = H; best_t = c; best_q = d - c; }
-                    else if (c >= best_t && (d - c) >= best_q) {
-                        const int tlen = c - best_t, qlen = (d - c) - best_q;
-                        const int l = tlen > qlen ? tlen - qlen : qlen - tlen;
-                        if (z >= 0 && best - H > z + l * ge) stopped = true;
-                    }
-                }
-            }
-        }
-        bool finished = alive && (stopped || final_step);
-
-        // carry dl 8..14 into the next step
-#pragma unroll
-        for (int x = 0; x < 7; x++) A[x] = A[8 + x];
-#pragma unroll
-        for (int x = 7; x < 15; x++) A[x] = INT_MIN;
-        cb_prev = cb;
-
-        // slots whose column block has left the band move on to column r + G*S
-        if (__any(any_adv)) {
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                if (adv[s]) {
-                    const int rn = rcur[s] + GS;
-                    rcur[s] = rn;
-                    init_col(rn, R, w, gapoe, ge, NEGK, h[s], f[s], corner[s]);
-                    if (!CMP) build_profile(prof0 + s * (8 * 64), rword[s], P.match, P.mismatch);
-                }
-            }
-        }
-
-        // next step / next slice (agatha_kernel.h:183-191, 330-334)
-        i++; y++;
-        if (y == sw) {
-            y = 0;
-            if (i >= total) final_step = true;
-            else {
-                ss = imax(imax(0, i - pql + 1), ((i * 8 + 8 - w) / 2) / 8);
-                se = imin(imin(prl - 1, i + sw - 1), (((i + sw - 1) * 8 + 7 + w) / 2) / 8);
-                if (ss > se) finished = alive;       // empty slice: stop without checking it (:189-191)
-            }
-        }
-        if (__builtin_expect(finished, 0)) {
-            if (k == 0) { La->score[pair] = best; La->qend[pair] = best_q; La->tend[pair] = best_t; }   // :359-363
-            alive = false;
-        }
-        } while (!__any(!alive && !exhausted));
-    }
-}
+#include "align_body.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // Length sort on the device (the reference does it on the host inside the timed region,

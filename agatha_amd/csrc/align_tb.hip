@@ -1,0 +1,160 @@
+// align_tb.hip -- traceback (alignment paths) for MI355X (gfx950, wave64).
+//
+// The reference declares gasal_res.cigar / n_cigar_ops (AGAThA/src/gasal.h:91-92) and never fills them (res.cpp:27-28);
+// SURVEY.md 8 f4 lists them as the step after the start positions.  Two kernels:
+//   * the int32 compare kernel of align_body.inc with TB = true: the same schedule, band, tie-breaks and z-drop as the
+//     scoring pass (it IS the scoring kernel), which additionally stores a 4-bit code per computed cell -- 32 bytes per
+//     8x8 block, written once, never re-read by the pass: a pure HBM write stream of 0.5 byte per cell;
+//   * backtrace_kernel: one thread per pair walks the codes from the end cell to the origin (a chain of dependent
+//     loads, Q + R long at most; the pairs of a batch run side by side) and writes the path as GASAL2-style bytes.
+// The CPU statement of both is oracle/agatha_oracle.c: agatha_model_traceback.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+
+#include "kernels.h"
+#include "device_common.h"
+
+namespace agatha {
+
+#include "align_body.inc"
+
+template <int G, int S>
+static hipError_t launch_tb_t(const AlignLaunch& L, hipStream_t st)
+{
+    const int groups_per_block = (256 / 64) * (64 / G);
+    int blocks = (L.n + groups_per_block - 1) / groups_per_block;
+    int max_blocks = L.num_cus * (S <= 3 ? 2 : 1);
+    if (L.max_blocks_override > 0) max_blocks = L.max_blocks_override;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((align_kernel<G, S, true, true>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p, -1, 0);
+    return hipGetLastError();
+}
+
+struct TbCfg { int G, S; hipError_t (*fn)(const AlignLaunch&, hipStream_t); };
+static const TbCfg kTbCfgs[] = {       // ascending G*S: the smallest one that holds the window is used
+    {16, 3, launch_tb_t<16, 3>}, {32, 3, launch_tb_t<32, 3>}, {64, 3, launch_tb_t<64, 3>}, {64, 6, launch_tb_t<64, 6>},
+};
+
+static const TbCfg* tb_cfg(int window_blocks)
+{
+    for (const TbCfg& c : kTbCfgs)
+        if (c.G * c.S >= window_blocks) return &c;
+    return nullptr;
+}
+
+int tb_group_slots(int window_blocks) { const TbCfg* c = tb_cfg(window_blocks); return c ? c->G * c->S : 0; }
+
+int tb_key_bits(int window_blocks)
+{
+    const TbCfg* c = tb_cfg(window_blocks);
+    if (!c) return -1;
+    int k = 7;
+    while ((1 << k) < 8 * (c->G * c->S + 2)) k++;
+    return k;
+}
+
+hipError_t launch_align_tb(const AlignLaunch& L, int window_blocks, hipStream_t st)
+{
+    const TbCfg* c = tb_cfg(window_blocks);
+    if (!c || !L.force_cmp || !L.tb_codes) return hipErrorInvalidValue;
+    return c->fn(L, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The walk.  States: 0 = in H of cell (i, j); 1 = in E(i, j) (target base j against a gap; E(i, j) was formed in cell
+// (i, j-1)); 2 = in F(i, j) (query base i against a gap; formed in cell (i-1, j)).  Gaps open from the DIAGONAL TERM of a
+// cell, not from its H, so leaving a gap always consumes the cell's diagonal.  Whatever is left of one sequence when the
+// other is used up lies against the boundary gap (H(i, -1) / H(-1, j), agatha_kernel.h:126-148).
+// A score that came through a cell the block-granular band skipped (the stale-register reads of agatha_kernel.h:33-35,
+// SURVEY.md App. B) belongs to no alignment: the walk meets a cell without a code and the pair gets
+// n_ops = 0xFFFFFFFF (AGATHA_AMD_NO_PATH), as does a pair whose result is AGATHA_AMD_BAD_RESULT.
+// Output bytes: (count << 2) | op, op 0 = match, 1 = mismatch, 2 = D, 3 = I, count <= 63, longer runs split greedily from
+// the start; first byte = first column of the alignment.  A pair with score 0 has an empty alignment: 0 bytes.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* __restrict__ n_ops)
+{
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= L.n) return;
+    const int score = L.score[pair];
+    const int Q = (int)L.qlens[pair], R = (int)L.tlens[pair];
+    if (score == INT_MIN) { n_ops[pair] = 0xFFFFFFFFu; return; }
+    if (score <= 0 || Q <= 0 || R <= 0) { n_ops[pair] = 0u; return; }
+    const uint32_t qo = L.qoffs[pair], to = L.toffs[pair];
+    const uint32_t* pq = L.packed_q + (qo >> 3);
+    const uint32_t* pt = L.packed_t + (to >> 3);
+    const uint32_t* tb = L.tb_codes + (size_t)pair * L.tb_pair_words;
+    uint8_t* out = cigar + (size_t)qo + (size_t)to;
+    const int w = L.p.band_width, sw = L.p.slice_width, W = (w + 7) >> 3;
+    const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
+
+    // code of cell (i, j), 0 if the scoring pass never computed it
+    auto code_of = [&](int i, int j) -> uint32_t {
+        const int q = i >> 3, r = j >> 3, step = q + r;
+        const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
+        const int i0 = (step / sw) * sw;                                  // first step of the slice (agatha_kernel.h:183-187)
+        const int ss = imax(imax(0, i0 - pql + 1), ((i0 * 8 + 8 - w) / 2) / 8);
+        const int se = imin(imin(prl - 1, i0 + sw - 1), (((i0 + sw - 1) * 8 + 7 + w) / 2) / 8);
+        if (r >= prl || q < cs || q > ce || r < ss || r > se) return 0u;
+        const uint32_t word = tb[((size_t)step * GS + (size_t)(r % GS)) * 8 + (i & 7)];
+        return (word >> (4 * (j & 7))) & 15u;
+    };
+    auto diag_op = [&](int i, int j) -> uint32_t {
+        const uint32_t a = (pq[i >> 3] >> (28 - 4 * (i & 7))) & 15u, b = (pt[j >> 3] >> (28 - 4 * (j & 7))) & 15u;
+        return (a == b && a != N_VALUE) ? 0u : 1u;
+    };
+    uint32_t nb = 0, run_op = 4u, run = 0;
+    auto emit = [&](uint32_t op) {
+        if (op == run_op && run < 63u) { run++; return; }
+        if (run) out[nb++] = (uint8_t)((run << 2) | run_op);
+        run_op = op; run = 1;
+    };
+
+    int i = L.qend[pair], j = L.tend[pair], state = 0;
+    bool bad = false;
+    for (int guard = Q + R + 16; i >= 0 && j >= 0 && guard > 0; guard--) {
+        uint32_t code = code_of(i, j);
+        if (code == 0u) { bad = true; break; }
+        if (state == 0) {
+            const uint32_t d = code & 3u;
+            if (d == 1u) { emit(diag_op(i, j)); i--; j--; }
+            else state = (int)d - 1;
+        } else if (state == 1) {
+            emit(2u); j--;
+            if (j < 0) break;
+            code = code_of(i, j);
+            if (code == 0u) { bad = true; break; }
+            if (!(code & 4u)) { emit(diag_op(i, j)); i--; j--; state = 0; }
+        } else {
+            emit(3u); i--;
+            if (i < 0) break;
+            code = code_of(i, j);
+            if (code == 0u) { bad = true; break; }
+            if (!(code & 8u)) { emit(diag_op(i, j)); i--; j--; state = 0; }
+        }
+    }
+    if (bad || (i >= 0 && j >= 0)) { n_ops[pair] = 0xFFFFFFFFu; return; }
+    for (; i >= 0; i--) emit(3u);
+    for (; j >= 0; j--) emit(2u);
+    if (run) out[nb++] = (uint8_t)((run << 2) | run_op);
+    // the bytes were produced end to start: turn them round, then move the short remainder of a split run behind its
+    // full bytes (greedy from the start, like the oracle)
+    for (uint32_t a = 0, b = nb - 1; a < b; a++, b--) { const uint8_t x = out[a]; out[a] = out[b]; out[b] = x; }
+    for (uint32_t a = 0; a < nb; ) {
+        uint32_t b = a;
+        while (b + 1 < nb && (out[b + 1] & 3u) == (out[a] & 3u)) b++;
+        if (b > a) { const uint8_t x = out[a]; out[a] = out[b]; out[b] = x; }
+        a = b + 1;
+    }
+    n_ops[pair] = nb;
+}
+
+hipError_t launch_backtrace(const AlignLaunch& L, int group_slots, uint8_t* cigar, uint32_t* n_ops, hipStream_t st)
+{
+    hipLaunchKernelGGL(backtrace_kernel, dim3((L.n + 63) / 64), dim3(64), 0, st, L, group_slots, cigar, n_ops);
+    return hipGetLastError();
+}
+
+}  // namespace agatha

@@ -166,12 +166,24 @@ int agatha_amd_seq_ops(void* stream, const uint8_t* d_unpacked, uint32_t* d_pack
     return 0;
 }
 
-int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
-                     const uint32_t* d_query_lens, const uint32_t* d_target_lens,
-                     const uint32_t* d_query_offsets, const uint32_t* d_target_offsets,
-                     uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
-                     const agatha_amd_scores* sc, int32_t* d_aln_score, int32_t* d_query_batch_end,
-                     int32_t* d_target_batch_end, void* d_workspace, size_t workspace_bytes)
+// blocks that can be live on one block-anti-diagonal: min(W + 1, ceil(Q/8), ceil(R/8))
+static long window_blocks(const agatha_amd_scores* sc, uint32_t max_query_len, uint32_t max_target_len)
+{
+    const long W = ((long)sc->band_width + 7) / 8;
+    long window = W + 1;
+    if (max_query_len) window = std::min(window, ((long)max_query_len + 7) / 8);
+    if (max_target_len) window = std::min(window, ((long)max_target_len + 7) / 8);
+    return std::max(window, 1L);
+}
+
+// tb_codes != nullptr: the traceback pass (every pair through the compare kernel, which also records the cell codes)
+static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
+                      const uint32_t* d_query_lens, const uint32_t* d_target_lens,
+                      const uint32_t* d_query_offsets, const uint32_t* d_target_offsets,
+                      uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
+                      const agatha_amd_scores* sc, int32_t* d_aln_score, int32_t* d_query_batch_end,
+                      int32_t* d_target_batch_end, void* d_workspace, size_t workspace_bytes,
+                      uint32_t* tb_codes, size_t tb_pair_words, agatha::AlignLaunch* L_out)
 {
     if (!d_packed_query || !d_packed_target || !d_query_lens || !d_target_lens || !d_query_offsets ||
         !d_target_offsets || !sc || !d_aln_score || !d_query_batch_end || !d_target_batch_end || !d_workspace)
@@ -180,17 +192,12 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     if (sc->slice_width < 1 || sc->band_width < 0 || sc->gap_extend < 0) return AGATHA_AMD_EINVAL;
     if (workspace_bytes < base_workspace_bytes(n_alns)) return AGATHA_AMD_EWORKSPACE;
 
-    // blocks that can be live on one block-anti-diagonal: min(W + 1, ceil(Q/8), ceil(R/8))
-    const long W = ((long)sc->band_width + 7) / 8;
-    long window = W + 1;
-    if (max_query_len) window = std::min(window, ((long)max_query_len + 7) / 8);
-    if (max_target_len) window = std::min(window, ((long)max_target_len + 7) / 8);
-    window = std::max(window, 1L);
+    const long window = window_blocks(sc, max_query_len, max_target_len);
     if (window > agatha::max_window_blocks()) return AGATHA_AMD_EBAND;
     // scores are carried as H << K in int32: the largest possible score -- and, with z-drop off, the deepest negative one --
     // must stay below 2^(30-K).  With length hints the whole call is refused here; without them (0 = unknown) the device
     // checks every pair and writes AGATHA_AMD_BAD_RESULT for the ones that do not fit (exotic_kernel, kind 3).
-    const int Kbits = agatha::key_bits_for_window((int)window);
+    const int Kbits = tb_codes ? agatha::tb_key_bits((int)window) : agatha::key_bits_for_window((int)window);
     if (Kbits < 0) return AGATHA_AMD_ERANGE;
     const long long score_limit = 1ll << (30 - Kbits);
     if (max_query_len || max_target_len) {
@@ -235,7 +242,8 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     L.exotic = exotic;
     L.kind_counts = queue + 12;
     L.score_limit = score_limit;
-    L.force_cmp = (sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
+    L.force_cmp = (tb_codes || sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
+    L.tb_codes = tb_codes; L.tb_pair_words = tb_pair_words;
     HIPCHK(agatha::launch_exotic(L, st));
     L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;
     L.mig_slot_dwords = 0;
@@ -269,9 +277,62 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
     }
     L.self_dev = rec;
     HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record, queue head reset, kernel choice; stream-ordered
+    if (L_out) *L_out = L;
+    if (tb_codes) { HIPCHK(agatha::launch_align_tb(L, (int)window, st)); return 0; }
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));
     HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st));
     if (g_ev1) HIPCHK(hipEventRecord(g_ev1, st));
+    return 0;
+}
+
+int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
+                     const uint32_t* d_query_lens, const uint32_t* d_target_lens,
+                     const uint32_t* d_query_offsets, const uint32_t* d_target_offsets,
+                     uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
+                     const agatha_amd_scores* sc, int32_t* d_aln_score, int32_t* d_query_batch_end,
+                     int32_t* d_target_batch_end, void* d_workspace, size_t workspace_bytes)
+{
+    return align_impl(stream, d_packed_query, d_packed_target, d_query_lens, d_target_lens, d_query_offsets, d_target_offsets,
+                      n_alns, max_query_len, max_target_len, sc, d_aln_score, d_query_batch_end, d_target_batch_end,
+                      d_workspace, workspace_bytes, nullptr, 0, nullptr);
+}
+
+size_t agatha_amd_traceback_pair_bytes(uint32_t max_query_len, uint32_t max_target_len, const agatha_amd_scores* sc)
+{
+    if (!sc || !max_query_len || !max_target_len || sc->band_width < 0) return 0;
+    const int gs = agatha::tb_group_slots((int)window_blocks(sc, max_query_len, max_target_len));
+    if (!gs) return 0;
+    // one 32-byte code block per (step, slot of the lane group); steps = block anti-diagonals of the longest pair
+    const size_t steps = ((size_t)max_query_len + 7) / 8 + ((size_t)max_target_len + 7) / 8;
+    return steps * (size_t)gs * 32;
+}
+
+int agatha_amd_align_traceback(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
+                               const uint32_t* d_query_lens, const uint32_t* d_target_lens,
+                               const uint32_t* d_query_offsets, const uint32_t* d_target_offsets,
+                               uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
+                               const agatha_amd_scores* sc, int32_t* d_aln_score, int32_t* d_query_batch_end,
+                               int32_t* d_target_batch_end, uint8_t* d_cigar, uint32_t* d_n_cigar_ops,
+                               void* d_workspace, size_t workspace_bytes, void* d_scratch, size_t scratch_bytes)
+{
+    if (!d_cigar || !d_n_cigar_ops || !d_scratch || !sc || n_alns == 0) return AGATHA_AMD_EINVAL;
+    if (!max_query_len || !max_target_len) return AGATHA_AMD_EINVAL;        // the code area is sized from the hints
+    const size_t pair_bytes = agatha_amd_traceback_pair_bytes(max_query_len, max_target_len, sc);
+    if (!pair_bytes) return AGATHA_AMD_EBAND;
+    const size_t per_pass = scratch_bytes / pair_bytes;
+    if (!per_pass) return AGATHA_AMD_EWORKSPACE;
+    const int gs = agatha::tb_group_slots((int)window_blocks(sc, max_query_len, max_target_len));
+    for (uint32_t a = 0; a < n_alns; ) {
+        const uint32_t m = (uint32_t)std::min<size_t>(per_pass, n_alns - a);
+        agatha::AlignLaunch L;
+        const int rc = align_impl(stream, d_packed_query, d_packed_target, d_query_lens + a, d_target_lens + a,
+                                  d_query_offsets + a, d_target_offsets + a, m, max_query_len, max_target_len, sc,
+                                  d_aln_score + a, d_query_batch_end + a, d_target_batch_end + a, d_workspace, workspace_bytes,
+                                  (uint32_t*)d_scratch, pair_bytes / 4, &L);
+        if (rc != 0) return rc;
+        HIPCHK(agatha::launch_backtrace(L, gs, d_cigar, d_n_cigar_ops + a, (hipStream_t)stream));
+        a += m;
+    }
     return 0;
 }
 

@@ -52,6 +52,10 @@ struct AlignLaunch {
     int* simd_steps;               // device: [2 workgroups][CU][SIMD] step counts the waves of a dealt single round tell each other
     int prio_duty;                 // of every 16 slices, the wave in slot 0 of its SIMD is the favoured one in this many
     unsigned int mig_test_delay_ticks;   // tests: odd lane groups sleep this long before they start (forces the take-over)
+    // ---- traceback pass (align_tb.hip): the compare kernel also records a 4-bit code per computed cell ----
+    uint32_t* tb_codes;            // device: tb_pair_words words per pair of the launch; 8 words (one per block row, a nibble
+                                   // per column) for (step, column block mod G*S) at ((step * G*S) + slot) * 8
+    size_t tb_pair_words;
 };
 
 // states of a boundary (the pair whose steps are split between lane groups b - 1 and b)
@@ -97,6 +101,14 @@ hipError_t launch_reverse_prefix(const uint32_t* packed, uint32_t* rev, const ui
                                  uint32_t* rev_lens, uint32_t n, hipStream_t st);
 hipError_t launch_starts(const int32_t* qend, const int32_t* tend, const int32_t* bq, const int32_t* bt, int32_t* qstart,
                          int32_t* tstart, uint32_t n, hipStream_t st);
+// Traceback pass (align_tb.hip).  tb_group_slots: G*S of the shape it uses for this window (0: band too wide);
+// tb_key_bits: the K of that shape (score range check); launch_align_tb: the compare kernel with code recording, for every
+// pair of the launch (L.force_cmp must be 1, L.tb_codes set); launch_backtrace: one thread per pair walks the codes from
+// (qend, tend) to the origin and writes GASAL2-style bytes at cigar + qoffs[pair] + toffs[pair].
+int tb_group_slots(int window_blocks);
+int tb_key_bits(int window_blocks);
+hipError_t launch_align_tb(const AlignLaunch& L, int window_blocks, hipStream_t st);
+hipError_t launch_backtrace(const AlignLaunch& L, int group_slots, uint8_t* cigar, uint32_t* n_ops, hipStream_t st);
 hipError_t launch_pack(const uint8_t* unpacked, uint32_t nbytes, uint32_t* packed, hipStream_t st);
 
 }  // namespace agatha

@@ -75,6 +75,10 @@ def load_library():
     lib.agatha_amd_starts_scratch_bytes.argtypes = [C.c_uint32] * 3
     lib.agatha_amd_align_starts.argtypes = [vp, u32p, u32p, u32p, u32p] + [C.c_uint32] * 5 + [C.POINTER(Scores)] + [i32p] * 4 + \
         [vp, C.c_size_t, vp, C.c_size_t]
+    lib.agatha_amd_traceback_pair_bytes.restype = C.c_size_t
+    lib.agatha_amd_traceback_pair_bytes.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Scores)]
+    lib.agatha_amd_align_traceback.argtypes = [vp, u32p, u32p, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.POINTER(Scores), i32p, i32p, i32p, vp, u32p, vp, C.c_size_t, vp, C.c_size_t]
     lib.agatha_amd_set_kernel_events.argtypes = [vp, vp]
     lib.agatha_amd_set_kernel_events.restype = None
     lib.agatha_amd_last_config.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -107,7 +111,8 @@ def load_library():
 EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack", "agatha_amd_pack_host",
-    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_starts_scratch_bytes", "agatha_amd_align_starts", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_starts_scratch_bytes", "agatha_amd_align_starts", "agatha_amd_traceback_pair_bytes",
+    "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -292,6 +297,42 @@ class DeviceBatch:
             scratch.free()
             for o in out:
                 o.free()
+
+    def align_traceback(self, scores, stream=None, scratch_bytes=None):
+        """Scores, end cells and alignment paths in one call (agatha_amd_align_traceback).  Returns (score, query_end,
+        target_end, cigars): cigars[k] is the bytes object of pair k ((count << 2) | op; 0 match, 1 mismatch, 2 D, 3 I), b''
+        for an empty alignment, None where the library reports AGATHA_AMD_NO_PATH.  scratch_bytes: device memory for the
+        cell codes (default: the whole batch in one pass, capped at 8 GiB; a smaller one means more passes).  Synchronises."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        m = self.d_meta
+        per = lib.agatha_amd_traceback_pair_bytes(self.max_qlen, self.max_tlen, C.byref(scores))
+        if per == 0:
+            raise AgathaError("traceback: band too wide or empty batch")
+        if scratch_bytes is None:
+            scratch_bytes = min(per * self.n, max(per, 8 << 30))
+        scratch = _DevBuf(lib, scratch_bytes)
+        cig = _DevBuf(lib, self.qbytes + self.tbytes + 16)
+        nops = _DevBuf(lib, 4 * self.n)
+        try:
+            _chk(lib, lib.agatha_amd_align_traceback(st, self.d_pk_q.ptr, self.d_pk_t.ptr, m[2].ptr, m[3].ptr, m[0].ptr, m[1].ptr,
+                                                     self.n, self.max_qlen, self.max_tlen, C.byref(scores), self.d_res[0].ptr,
+                                                     self.d_res[1].ptr, self.d_res[2].ptr, cig.ptr, nops.ptr, self.d_ws.ptr,
+                                                     self.ws_bytes, scratch.ptr, scratch_bytes))
+            h_cig = np.zeros(self.qbytes + self.tbytes, np.uint8)
+            h_n = np.zeros(self.n, np.uint32)
+            _chk(lib, lib.agatha_amd_memcpy_d2h_async(st, h_cig.ctypes.data, cig.ptr, h_cig.nbytes))
+            _chk(lib, lib.agatha_amd_memcpy_d2h_async(st, h_n.ctypes.data, nops.ptr, h_n.nbytes))
+            self.download(st)
+            _chk(lib, lib.agatha_amd_stream_synchronize(st))
+            res = self.res_host.copy()
+            off = self.host[2].astype(np.int64) + self.host[3].astype(np.int64)
+            cigars = [None if k == 0xFFFFFFFF else h_cig[o:o + k].tobytes() for o, k in zip(off, h_n.astype(np.int64))]
+            return res[0], res[1], res[2], cigars
+        finally:
+            scratch.free()
+            cig.free()
+            nops.free()
 
     def kernel_choice(self, stream=None):
         """("int32" | "int16", lanes per pair, slots per lane) of the kernel the device chose for the plain pairs."""

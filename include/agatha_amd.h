@@ -116,6 +116,33 @@ int agatha_amd_align_starts(void* stream, const uint32_t* d_packed_query, const 
                             int32_t* d_query_batch_start, int32_t* d_target_batch_start, void* d_workspace,
                             size_t workspace_bytes, void* d_scratch, size_t scratch_bytes);
 
+/* Alignment paths: fills the result members the reference declares and never fills (cigar / n_cigar_ops, gasal.h:91-92,
+ * res.cpp:27-28), in the byte format GASAL2 publishes for them: pair k's path is d_n_cigar_ops[k] bytes starting at
+ * d_cigar + d_query_offsets[k] + d_target_offsets[k] (so d_cigar needs query_batch_bytes + target_batch_bytes of the
+ * unpacked layout), one byte per run, (count << 2) | op with op 0 = match, 1 = mismatch, 2 = D (target base against a
+ * gap), 3 = I (query base against a gap), count <= 63, longer runs split greedily from the start; the first byte is the
+ * alignment's first column -- always the origin, this being an extension alignment -- and the last its end cell.
+ * The call is a complete agatha_amd_align() of the batch (it also writes score / ends, bit-identical to that call) through
+ * a variant of the kernel that records a 4-bit code per cell, followed by the walk back from every end cell; it replaces
+ * that call rather than following it.  The path is the one the recurrence took: ties diagonal > E > F, open before extend.
+ * d_n_cigar_ops[k] = 0 for an empty alignment (score 0), AGATHA_AMD_NO_PATH for a pair whose result is
+ * AGATHA_AMD_BAD_RESULT or whose score came through a cell the reference's block-granular band skips (the stale-register
+ * reads of agatha_kernel.h:33-35: such a score belongs to no alignment; rare, needs a path along the band edge).
+ * max_query_len / max_target_len are REQUIRED here (non-zero, true upper bounds): they size the code area.
+ * d_scratch: any multiple (>= 1) of agatha_amd_traceback_pair_bytes() -- the batch is processed in passes of
+ * scratch_bytes / pair_bytes pairs, so a small scratch costs launches, not correctness.  d_workspace as for agatha_amd_align. */
+#define AGATHA_AMD_NO_PATH 0xFFFFFFFFu
+size_t agatha_amd_traceback_pair_bytes(uint32_t max_query_len, uint32_t max_target_len, const agatha_amd_scores* scores);
+int agatha_amd_align_traceback(void* stream,
+                               const uint32_t* d_packed_query, const uint32_t* d_packed_target,
+                               const uint32_t* d_query_lens, const uint32_t* d_target_lens,
+                               const uint32_t* d_query_offsets, const uint32_t* d_target_offsets,
+                               uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
+                               const agatha_amd_scores* scores,
+                               int32_t* d_aln_score, int32_t* d_query_batch_end, int32_t* d_target_batch_end,
+                               uint8_t* d_cigar, uint32_t* d_n_cigar_ops,
+                               void* d_workspace, size_t workspace_bytes, void* d_scratch, size_t scratch_bytes);
+
 /* Optional: a hipEvent_t pair (as void*) that the NEXT agatha_amd_align() calls of this thread record directly
  * around the alignment kernel launch (excluding the sort); pass NULLs to switch it off.  Used by bench.py for
  * the per-kernel duration of the roofline line. */

@@ -118,7 +118,14 @@ typedef struct {
     dmax_t *dmax; int dmax_mod;            /* ring size (power of two not required here) */
     const uint8_t *qc, *rc;
     int Q, R, a, b, gapoe, ge, w, wide;
+    uint8_t *tb; int tb_half;              /* traceback codes of the computed cells, band-indexed (NULL: not recorded) */
 } ctx_t;
+
+/* Traceback code of a cell (not in the reference, which never fills gasal_res.cigar, gasal.h:91-92):
+ * bits 0-1 = which term H took (1 the diagonal term t, 2 E, 3 F; on ties in that order; 0 = the cell was never computed),
+ * bit 2 = the E that leaves the cell to the right extends the E that entered it (e - ge > t - gapoe, opening wins ties),
+ * bit 3 = the same for F. */
+static inline size_t tb_index(const ctx_t *cx, int i, int c) { return (size_t)i * (size_t)(2 * cx->tb_half + 1) + (size_t)(c - i + cx->tb_half); }
 
 static void block_rows(ctx_t *cx, int q, int r, int cs, int ce, int32_t *h, int32_t *f, int32_t *p)
 {
@@ -135,6 +142,12 @@ static void block_rows(ctx_t *cx, int q, int r, int cs, int ce, int32_t *h, int3
             } else {
                 int t = sub_score(qb, cx->rc[c], cx->a, cx->b) + p[m];
                 h[m] = imax(imax(t, f[m]), e);
+                if (cx->tb) {
+                    int code = (h[m] == t) ? 1 : (h[m] == e ? 2 : 3);
+                    if (e - cx->ge > t - cx->gapoe) code |= 4;
+                    if (f[m] - cx->ge > t - cx->gapoe) code |= 8;
+                    cx->tb[tb_index(cx, i, c)] = (uint8_t)code;
+                }
                 f[m] = imax(t - cx->gapoe, f[m] - cx->ge);
                 e = imax(t - cx->gapoe, e - cx->ge);
                 p[m] = h[m - 1];
@@ -192,7 +205,7 @@ static int setup_ctx(ctx_t *cx, const char *qs, int Q, const char *rs, int R, co
     for (int i = 0; i < ring; i++) dmax_reset(&cx->dmax[i]);
     cx->qc = *qc; cx->rc = *rc; cx->Q = Q; cx->R = R;
     cx->a = pr->match; cx->b = pr->mismatch; cx->gapoe = pr->gap_open + pr->gap_extend; cx->ge = pr->gap_extend;
-    cx->w = pr->band_width; cx->wide = wide;
+    cx->w = pr->band_width; cx->wide = wide; cx->tb = NULL; cx->tb_half = 0;
     init_strips(cx, L);
     return L;
 }
@@ -200,13 +213,14 @@ static int setup_ctx(ctx_t *cx, const char *qs, int Q, const char *rs, int R, co
 /* ------------------------------------------------------------------------------------------ */
 /* Literal slice/pass order.                                            */
 /* ------------------------------------------------------------------------------------------ */
-void agatha_model_slices(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr,
-                         int wide, oracle_result_t *out)
+static void model_slices(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr,
+                         int wide, oracle_result_t *out, uint8_t *tb, int tb_half)
 {
     ctx_t cx; uint8_t *qc, *rc;
     const int sw = pr->slice_width, w = pr->band_width, z = pr->z_threshold, ge = pr->gap_extend;
     const int ring = 8 * (sw + 1);                                  /* total_shm, :83 */
     setup_ctx(&cx, qs, Q, rs, R, pr, wide, &qc, &rc, ring);
+    cx.tb = tb; cx.tb_half = tb_half;
     const int pql = (Q + 7) / 8, prl = (R + 7) / 8;
     int total = prl + pql - 1;                                      /* :165 */
     zstate_t zs = {0, 0, 0, 0};
@@ -254,6 +268,80 @@ void agatha_model_slices(const char *qs, int Q, const char *rs, int R, const ora
     }
     out->score = zs.best; out->query_end = zs.best_q; out->target_end = zs.best_t;   /* :359-363 */
     free(cx.rowH); free(cx.dmax); free(qc); free(rc);
+}
+
+void agatha_model_slices(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr,
+                         int wide, oracle_result_t *out)
+{
+    model_slices(qs, Q, rs, R, pr, wide, out, NULL, 0);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Traceback.  The reference declares gasal_res.cigar / n_cigar_ops (gasal.h:91-92) and never fills    */
+/* them (res.cpp:27-28); GASAL2, which it derives from, publishes the byte format used here: one byte per run,           */
+/* (count << 2) | op with op 0 = match, 1 = mismatch, 2 = D (target base against a gap), 3 = I (query base against a     */
+/* gap), count <= 63, longer runs split greedily from the start; the bytes run from the alignment's first column (always */
+/* the origin: this is an extension alignment) to its end cell (query_end, target_end).                                   */
+/* The path is the one the recurrence of block_rows() took, with its tie-breaks (diagonal, then E, then F; opening a     */
+/* gap before extending one) and its rule that gaps open from the diagonal TERM of a cell, not from its H.               */
+/* A pair whose score is 0 never had a positive cell: its alignment is empty (0 ops).                                    */
+/* The reference's block-granular band lets a boundary block read the stale register of a cell it skipped                */
+/* (agatha_kernel.h:33-35): the few scores that come through such a cell belong to no alignment, the    */
+/* walk then meets a cell that was never computed and the pair is reported as having no path.                             */
+/* Returns the number of bytes written, or -1 (no path, or `cap` too small).                                              */
+/* ------------------------------------------------------------------------------------------ */
+static int tb_is_match(const uint8_t *qc, const uint8_t *rc, int i, int j)
+{
+    return qc[i] == rc[j] && qc[i] != N_VALUE;
+}
+
+int agatha_model_traceback(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr,
+                           oracle_result_t *out, uint8_t *cigar, int cap)
+{
+    const int half = pr->band_width + 16;
+    if (Q <= 0 || R <= 0) { out->score = 0; out->query_end = 0; out->target_end = 0; return 0; }
+    uint8_t *tb = (uint8_t *)malloc((size_t)Q * (size_t)(2 * half + 1));
+    memset(tb, 0, (size_t)Q * (size_t)(2 * half + 1));
+    model_slices(qs, Q, rs, R, pr, 1, out, tb, half);
+    if (out->score <= 0) { free(tb); return 0; }
+    ctx_t ix; ix.tb_half = half;
+    int qp, rp;
+    uint8_t *qc = encode_padded(qs, Q, &qp), *rc = encode_padded(rs, R, &rp);
+    uint8_t *ops = (uint8_t *)malloc((size_t)Q + (size_t)R + 8);     /* single ops, end to start */
+    int n = 0, i = out->query_end, j = out->target_end, state = 0, bad = 0;
+    while (i >= 0 && j >= 0 && !bad) {
+        int code = tb[tb_index(&ix, i, j)];
+        if (code == 0) { bad = 1; break; }
+        if (state == 0) {
+            int d = code & 3;
+            if (d == 1) { ops[n++] = tb_is_match(qc, rc, i, j) ? 0 : 1; i--; j--; }
+            else state = d - 1;                   /* 1: H = E(i, j), 2: H = F(i, j) */
+        } else if (state == 1) {                  /* E(i, j): target base j against a gap; formed in cell (i, j - 1) */
+            ops[n++] = 2; j--;
+            if (j < 0) break;                     /* opened from the boundary column H(i, -1) */
+            code = tb[tb_index(&ix, i, j)];
+            if (code == 0) { bad = 1; break; }
+            if (!(code & 4)) { ops[n++] = tb_is_match(qc, rc, i, j) ? 0 : 1; i--; j--; state = 0; }
+        } else {                                  /* F(i, j): query base i against a gap; formed in cell (i - 1, j) */
+            ops[n++] = 3; i--;
+            if (i < 0) break;                     /* opened from the boundary row H(-1, j) */
+            code = tb[tb_index(&ix, i, j)];
+            if (code == 0) { bad = 1; break; }
+            if (!(code & 8)) { ops[n++] = tb_is_match(qc, rc, i, j) ? 0 : 1; i--; j--; state = 0; }
+        }
+    }
+    /* what is left of one sequence lies against the boundary gap */
+    while (!bad && i >= 0) { ops[n++] = 3; i--; }
+    while (!bad && j >= 0) { ops[n++] = 2; j--; }
+    int nb = 0;
+    for (int k = n - 1; k >= 0 && !bad; ) {
+        int op = ops[k], run = 0;
+        while (k >= 0 && ops[k] == op && run < 63) { run++; k--; }
+        if (nb >= cap) { bad = 1; break; }
+        cigar[nb++] = (uint8_t)((run << 2) | op);
+    }
+    free(ops); free(tb); free(qc); free(rc);
+    return bad ? -1 : nb;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -399,6 +487,27 @@ void agatha_oracle_batch(const uint8_t *qbatch, const uint8_t *tbatch,
         if (model == 0) agatha_model_slices(q, (int)qlen[k], t, (int)tlen[k], pr, wide, &res);
         else if (model == 1) agatha_model_steps(q, (int)qlen[k], t, (int)tlen[k], pr, wide, &res);
         else agatha_model_exactband(q, (int)qlen[k], t, (int)tlen[k], pr, &res);
+        score[k] = res.score; qend[k] = res.query_end; tend[k] = res.target_end;
+    }
+}
+
+/* traceback over a host batch: pair k's bytes start at cigar + cigar_off[k], n_ops[k] of them (-1: failed) */
+void agatha_traceback_batch(const uint8_t *qbatch, const uint8_t *tbatch,
+                            const uint32_t *qoff, const uint32_t *toff,
+                            const uint32_t *qlen, const uint32_t *tlen, int n,
+                            const oracle_params_t *pr, int threads,
+                            int32_t *score, int32_t *qend, int32_t *tend,
+                            uint8_t *cigar, const uint64_t *cigar_off, int32_t *n_ops)
+{
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int k = 0; k < n; k++) {
+        oracle_result_t res;
+        const char *q = (const char *)qbatch + qoff[k], *t = (const char *)tbatch + toff[k];
+        n_ops[k] = agatha_model_traceback(q, (int)qlen[k], t, (int)tlen[k], pr, &res, cigar + cigar_off[k],
+                                          (int)qlen[k] + (int)tlen[k] + 8);
         score[k] = res.score; qend[k] = res.query_end; tend[k] = res.target_end;
     }
 }

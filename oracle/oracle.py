@@ -54,6 +54,8 @@ def lib():
         _lib.ksw_style_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p,
                                                             C.c_void_p, C.POINTER(C.c_int)]
         _lib.ksw_style_batch.restype = None
+        _lib.agatha_traceback_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int] + [C.c_void_p] * 6
+        _lib.agatha_traceback_batch.restype = None
         for f in (_lib.agatha_ref_seq_ops_as_written, _lib.agatha_seq_ops_product_semantics):
             f.argtypes = [C.c_void_p] * 4 + [C.c_int]
             f.restype = None
@@ -153,6 +155,56 @@ def start_positions(queries, targets, params, qend, tend, threads=1):
     back = Params(params.match, params.mismatch, params.gap_open, params.gap_extend, params.slice_width, -1, params.band_width)
     s, q, t = align_pairs(rq, rt, back, wide=True, model=MODEL_SLICES, threads=threads)
     return np.asarray(qend, np.int32) - q, np.asarray(tend, np.int32) - t, s
+
+
+def traceback_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, threads=1):
+    """Alignment paths (agatha_model_traceback: the cigar / n_cigar_ops members the reference declares, gasal.h:91-92, and
+    never fills).  Returns (score, query_end, target_end, cigar, n_ops): pair k's bytes are
+    cigar[qoff[k] + toff[k] : ... + n_ops[k]], each (count << 2) | op, op 0 match / 1 mismatch / 2 D / 3 I."""
+    n = len(qlen)
+    qbuf, tbuf = np.ascontiguousarray(qbuf, np.uint8), np.ascontiguousarray(tbuf, np.uint8)
+    qoff, toff, qlen, tlen = (np.ascontiguousarray(a, np.uint32) for a in (qoff, toff, qlen, tlen))
+    score, qend, tend, nops = (np.zeros(n, np.int32) for _ in range(4))
+    off = qoff.astype(np.uint64) + toff.astype(np.uint64)
+    cigar = np.zeros(int(qbuf.size + tbuf.size) + 16, np.uint8)
+    lib().agatha_traceback_batch(qbuf.ctypes.data, tbuf.ctypes.data, qoff.ctypes.data, toff.ctypes.data, qlen.ctypes.data,
+                                 tlen.ctypes.data, n, C.byref(params), threads, score.ctypes.data, qend.ctypes.data,
+                                 tend.ctypes.data, cigar.ctypes.data, off.ctypes.data, nops.ctypes.data)
+    return score, qend, tend, cigar, nops
+
+
+def traceback_pairs(queries, targets, params, threads=1):
+    """-> (score, query_end, target_end, [cigar bytes of each pair])"""
+    qb, qo, ql = make_batch(queries)
+    tb, to, tl = make_batch(targets)
+    s, qe, te, cig, nops = traceback_batch(qb, tb, qo, to, ql, tl, params, threads)
+    off = qo.astype(np.int64) + to.astype(np.int64)
+    return s, qe, te, [cig[o:o + k].tobytes() if k >= 0 else None for o, k in zip(off, nops)]    # None: no path
+
+
+def cigar_rescore(cigar, query, target, params):
+    """Independent check of a cigar: walks both sequences from the origin and returns (score, query bases used, target
+    bases used) under the affine scoring of the recurrence (a gap of length L costs gap_open + L * gap_extend; a base
+    against N, or N against anything, scores -1: gasal_kernels.h:48-50).  Raises if an op byte contradicts the bases."""
+    i = j = 0
+    score = 0
+    prev = -1
+    for byte in cigar:
+        op, cnt = byte & 3, byte >> 2
+        assert cnt >= 1
+        if op in (0, 1):
+            for _ in range(cnt):
+                a, b = query[i] & 15, (target[j] & 15 if j < len(target) else 14)     # target_end can lie in the N padding
+                same = a == b and a != 14
+                assert same == (op == 0), (i, j, op)
+                score += -1 if (a == 14 or b == 14) else (params.match if a == b else -params.mismatch)
+                i += 1; j += 1
+        else:
+            score -= cnt * params.gap_extend + (0 if prev == op else params.gap_open)
+            if op == 2: j += cnt
+            else: i += cnt
+        prev = op
+    return score, i, j
 
 
 def pack(unpacked):
