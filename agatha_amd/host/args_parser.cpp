@@ -12,7 +12,7 @@
 Parameters::Parameters(int argc_, char** argv_)
     : sa(2), sb(4), gapo(4), gape(2), print_out(0), n_threads(1), slice_width(3), z_threshold(400), band_width(751),
       kernel_block_num(256), kernel_thread_num(256), kernel_align_num(8192), isPacked(false),
-      isReverseComplement(false), start_pos(0), n_gpus(1), argc(argc_), argv(argv_)
+      isReverseComplement(false), start_pos(0), traceback(0), n_gpus(1), argc(argc_), argv(argv_)
 {
 }
 
@@ -70,6 +70,7 @@ void Parameters::help()
     std::cerr << "         -c        apply the reverse/complement codes of the FASTA header characters (> < / +)" << std::endl;
     std::cerr << "         -k        pack the sequences on the host and ship pre-packed batches (isPacked): half the H2D bytes" << std::endl;
     std::cerr << "         -S        also compute and print the start positions (query_batch_start / target_batch_start)" << std::endl;
+    std::cerr << "         -T        also compute and print the alignment paths (cigar / n_cigar_ops)" << std::endl;
     std::cerr << "         -g INT    spread the CPU threads over this many GPUs [" << n_gpus << "]" << std::endl;
     std::cerr << "         --help, -h : displays this message." << std::endl;
     std::cerr << "Single-pack multi-Parameters (e.g. -sp) is not supported." << std::endl;
@@ -101,6 +102,7 @@ void Parameters::parse()
             case 'g': n_gpus = next_int(c); break;
             case 'k': isPacked = true; break;
             case 'S': start_pos = 1; break;
+            case 'T': traceback = 1; break;
             case 's': slice_width = next_int(c); break;
             case 'z': z_threshold = next_int(c); break;
             case 'w': band_width = next_int(c); break;

@@ -108,6 +108,7 @@ void gasal_res_destroy_host(gasal_res_t* r)
     if (!r) return;
     pin_free(r->aln_score); pin_free(r->query_batch_start); pin_free(r->target_batch_start);
     pin_free(r->query_batch_end); pin_free(r->target_batch_end);
+    pin_free(r->cigar); pin_free(r->n_cigar_ops);
     free(r);
 }
 void gasal_res_destroy_device(gasal_res_t* device_res, gasal_res_t* device_cpy)
@@ -116,6 +117,7 @@ void gasal_res_destroy_device(gasal_res_t* device_res, gasal_res_t* device_cpy)
     if (!device_cpy) return;
     dev_free(device_cpy->aln_score); dev_free(device_cpy->query_batch_start); dev_free(device_cpy->target_batch_start);
     dev_free(device_cpy->query_batch_end); dev_free(device_cpy->target_batch_end);
+    dev_free(device_cpy->cigar); dev_free(device_cpy->n_cigar_ops);
     free(device_cpy);
 }
 
@@ -318,7 +320,7 @@ void gasal_destroy_streams(gasal_gpu_storage_v* vec, Parameters* params)
         pin_free(s->host_query_batch_offsets); pin_free(s->host_target_batch_offsets);
         pin_free(s->host_query_batch_lens); pin_free(s->host_target_batch_lens);
         free_device_meta(s);
-        dev_free(s->starts_scratch);
+        dev_free(s->starts_scratch); dev_free(s->tb_scratch);
         dev_free(s->unpacked_query_batch); dev_free(s->unpacked_target_batch);
         if (!params->isPacked) { dev_free(s->packed_query_batch); dev_free(s->packed_target_batch); }
         if (s->ev_begin) CHK(agatha_amd_event_destroy(s->ev_begin));
@@ -445,11 +447,43 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
 
     // sort + align; with -p the pair of events brackets them ON THIS STREAM (the reference brackets them on the
     // default stream and then device-synchronises, serialising its two streams: gasal_align.cu:219-236)
+    if (params->traceback) {
+        // alignment paths (extension; cigar / n_cigar_ops are declared and left NULL by the reference, gasal.h:91-92): the
+        // result arrays and the code scratch are made on first use and grown with the batch
+        const size_t cb = (size_t)s->gpu_max_query_batch_bytes + s->gpu_max_target_batch_bytes + 16;
+        if (!s->host_res->cigar || !s->device_cpy->cigar || s->cigar_bytes < cb || s->cigar_alns < s->gpu_max_n_alns) {
+            CHK(agatha_amd_stream_synchronize(s->str));
+            pin_free(s->host_res->cigar); pin_free(s->host_res->n_cigar_ops);
+            dev_free(s->device_cpy->cigar); dev_free(s->device_cpy->n_cigar_ops);
+            s->host_res->cigar = pin_alloc<uint8_t>(cb);      s->host_res->n_cigar_ops = pin_alloc<uint32_t>(s->gpu_max_n_alns);
+            s->device_cpy->cigar = dev_alloc<uint8_t>(cb);    s->device_cpy->n_cigar_ops = dev_alloc<uint32_t>(s->gpu_max_n_alns);
+            s->cigar_bytes = cb; s->cigar_alns = s->gpu_max_n_alns;
+        }
+        const size_t per = agatha_amd_traceback_pair_bytes(max_q, max_t, &sc);
+        if (per == 0) {
+            fprintf(stderr, "[GASAL ERROR:] traceback: band width %d is too wide for sequences this long\n", g_scores.band_width);
+            exit(EXIT_FAILURE);
+        }
+        // the whole batch in one pass if that takes at most 16 GiB, otherwise in passes of 16 GiB
+        const size_t want = std::max(per, std::min(per * (size_t)actual_n_alns, (size_t)16 << 30));
+        if (s->tb_scratch_bytes < want) {
+            CHK(agatha_amd_stream_synchronize(s->str));
+            dev_free(s->tb_scratch);
+            s->tb_scratch = dev_alloc<uint8_t>(want);
+            s->tb_scratch_bytes = want;
+        }
+    }
     if (params->print_out) CHK(agatha_amd_event_record(s->ev_begin, s->str));
-    int rc = agatha_amd_align(s->str, s->packed_query_batch, s->packed_target_batch, s->query_batch_lens,
-                              s->target_batch_lens, s->query_batch_offsets, s->target_batch_offsets, actual_n_alns,
-                              max_q, max_t, &sc, s->device_cpy->aln_score, s->device_cpy->query_batch_end,
-                              s->device_cpy->target_batch_end, s->workspace, s->workspace_bytes);
+    int rc = params->traceback
+        ? agatha_amd_align_traceback(s->str, s->packed_query_batch, s->packed_target_batch, s->query_batch_lens,
+                                     s->target_batch_lens, s->query_batch_offsets, s->target_batch_offsets, actual_n_alns,
+                                     max_q, max_t, &sc, s->device_cpy->aln_score, s->device_cpy->query_batch_end,
+                                     s->device_cpy->target_batch_end, s->device_cpy->cigar, s->device_cpy->n_cigar_ops,
+                                     s->workspace, s->workspace_bytes, s->tb_scratch, s->tb_scratch_bytes)
+        : agatha_amd_align(s->str, s->packed_query_batch, s->packed_target_batch, s->query_batch_lens,
+                           s->target_batch_lens, s->query_batch_offsets, s->target_batch_offsets, actual_n_alns,
+                           max_q, max_t, &sc, s->device_cpy->aln_score, s->device_cpy->query_batch_end,
+                           s->device_cpy->target_batch_end, s->workspace, s->workspace_bytes);
     if (rc == AGATHA_AMD_EBAND) {
         fprintf(stderr, "[GASAL ERROR:] band width %d exceeds the largest supported band (%d) for sequences this long\n",
                 g_scores.band_width, agatha_amd_max_band());
@@ -487,6 +521,11 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
         CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->query_batch_start, s->device_cpy->query_batch_start, rb));
     if (s->host_res->target_batch_start && s->device_cpy->target_batch_start)
         CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->target_batch_start, s->device_cpy->target_batch_start, rb));
+    if (params->traceback) {
+        CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->n_cigar_ops, s->device_cpy->n_cigar_ops, rb));
+        CHK(agatha_amd_memcpy_d2h_async(s->str, s->host_res->cigar, s->device_cpy->cigar,
+                                        (size_t)actual_query_batch_bytes + actual_target_batch_bytes));
+    }
     s->is_free = 0;
 }
 

@@ -148,6 +148,22 @@ int main(int argc, char** argv)
                                 if (args->start_pos)        // -S (extension)
                                     std::cout << "\tquery_batch_start=" << r->query_batch_start[j] << "\ttarget_batch_start="
                                               << r->target_batch_start[j];
+                                if (args->traceback) {      // -T (extension): the path as CIGAR text (=, X, D, I)
+                                    const gasal_gpu_storage_t* st = slot[z].st;
+                                    const uint32_t nops = r->n_cigar_ops[j];
+                                    std::cout << "\tcigar=";
+                                    if (nops == 0xFFFFFFFFu) std::cout << "!";
+                                    else if (nops == 0) std::cout << "*";
+                                    else {
+                                        const uint8_t* c = r->cigar + st->host_query_batch_offsets[j] + st->host_target_batch_offsets[j];
+                                        uint32_t run = 0, op = 4;
+                                        for (uint32_t b = 0; b <= nops; b++) {
+                                            const uint32_t o = b < nops ? (c[b] & 3u) : 5u;
+                                            if (o != op) { if (run) std::cout << run << "=XDI"[op]; run = 0; op = o; }
+                                            if (b < nops) run += c[b] >> 2;
+                                        }
+                                    }
+                                }
                                 std::cout << std::endl;
                             }
                         }

@@ -45,7 +45,10 @@ struct host_batch {
 typedef struct host_batch host_batch_t;
 
 /* result arrays (gasal.h:85-94).  The reference leaves the start members NULL (res.cpp:27-28); here they are allocated and
- * filled when params->start_pos is set (extension, CLI flag -S: GASAL2's WITH_START, gasal.h:36); cigar members stay NULL */
+ * filled when params->start_pos is set (extension, CLI flag -S: GASAL2's WITH_START, gasal.h:36), and the cigar members
+ * when params->traceback is set (extension, CLI flag -T): pair k's path is n_cigar_ops[k] bytes at
+ * cigar + host_query_batch_offsets[k] + host_target_batch_offsets[k], byte = (count << 2) | op, op 0 match / 1 mismatch /
+ * 2 D / 3 I (include/agatha_amd.h: agatha_amd_align_traceback); n_cigar_ops[k] = 0xFFFFFFFF: no path */
 struct gasal_res {
     int32_t* aln_score;
     int32_t* query_batch_end;
@@ -119,6 +122,10 @@ typedef struct {
     int timing_pending;
     void* starts_scratch;               /* device scratch of agatha_amd_align_starts (only with params->start_pos) */
     size_t starts_scratch_bytes;
+    void* tb_scratch;                   /* device scratch of agatha_amd_align_traceback (only with params->traceback) */
+    size_t tb_scratch_bytes;
+    size_t cigar_bytes;                 /* capacity of host_res->cigar / device_cpy->cigar */
+    uint32_t cigar_alns;                /* capacity of host_res->n_cigar_ops / device_cpy->n_cigar_ops */
     void* timing_params;                /* Parameters* of the batch in flight: its raw_file gets the -p line */
     int is_free;
     int id;
@@ -150,6 +157,7 @@ class Parameters {
     bool isPacked;
     bool isReverseComplement;
     int start_pos;                      /* extension (-S): also compute query_batch_start / target_batch_start (WITH_START, gasal.h:36) */
+    int traceback;                      /* extension (-T): also compute the alignment paths (cigar / n_cigar_ops, gasal.h:91-92) */
     int n_gpus;                         /* extension (-g): host threads are spread over this many GPUs (gasal_set_device) */
     std::string query_batch_fasta_filename, target_batch_fasta_filename, raw_filename;
     std::ifstream query_batch_fasta, target_batch_fasta;

@@ -202,6 +202,48 @@ def test_cli_start_positions(tmp_path):
     assert (exp[:, 3] > 0).sum() > 30
 
 
+def cigar_text(c):
+    """CIGAR text of a path in the byte format of include/agatha_amd.h (runs the format split are merged again)."""
+    if c is None:
+        return "!"
+    if not c:
+        return "*"
+    out, run, op = [], 0, c[0] & 3
+    for b in c:
+        if (b & 3) != op:
+            out.append(f"{run}{'=XDI'[op]}")
+            run, op = 0, b & 3
+        run += b >> 2
+    out.append(f"{run}{'=XDI'[op]}")
+    return "".join(out)
+
+
+def test_cli_traceback(tmp_path):
+    """f4 through the GASAL API: `manual -p -T` fills host_res->cigar / n_cigar_ops (declared and left NULL by the reference,
+    gasal.h:91-92) and prints every path as CIGAR text; three batches per stream, so the arrays are reused."""
+    qs, ts = synth.make_pairs(19, 130, lambda r: int(r.integers(1, 2500)))
+    qs[5], ts[5] = b"ACGT" * 25, b"TGCA" * 25                       # empty alignment: "*"
+    f1, f2, raw = tmp_path / "a.fa", tmp_path / "b.fa", tmp_path / "raw.log"
+    write_fasta(f1, qs, header=">")
+    write_fasta(f2, ts, header=">")
+    r = subprocess.run([MANUAL, "-p", "-T", "-w", "120", "-z", "300", "-a", "25", str(f1), str(f2), str(raw)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    P = O.make_params(w=120, z=300)
+    es, eq, et, cig = O.traceback_pairs(qs, ts, P, threads=4)
+    exp = [f"{s}\tquery_batch_end={a}\ttarget_batch_end={b}\tcigar={cigar_text(c)}" for s, a, b, c in zip(es, eq, et, cig)]
+    got = r.stdout.strip().splitlines()
+    assert len(got) == len(exp)
+    blocks, unused = [exp[k:k + 25] for k in range(0, 130, 25)], list(range(6))
+    pos = 0
+    while pos < len(got):                                           # batches print in the order their streams finish
+        hit = [k for k in unused if got[pos:pos + len(blocks[k])] == blocks[k]]
+        assert hit, (pos, got[pos], )
+        pos += len(blocks[hit[0]])
+        unused.remove(hit[0])
+    assert sum("D" in e or "I" in e for e in exp) > 60 and any(e.endswith("cigar=*") for e in exp)
+
+
 def test_cli_batch_larger_than_one_round_of_lane_groups(tmp_path):
     """`manual -a 12000` on 11 000 short pairs at a narrow band: one GASAL batch holds more pairs than the int16 kernel has
     lane groups (8192), so the C++ layer's workspace carries the areas of the preemptive schedule and pairs are suspended

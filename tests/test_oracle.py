@@ -230,3 +230,73 @@ def test_start_positions_definition():
     qs_, ts_, back = O.start_positions(qs, ts, P, qe, te)
     assert s.tolist()[0] == 800 and qs_.tolist() == [0, 30, 0, 0] and ts_.tolist() == [0, 0, 30, 0]
     assert (back >= s).all() and back.tolist()[1] == 800
+
+
+def _full_dp_best_path_score(q, t, P, qe, te):
+    """Unbanded Gotoh DP in plain Python (small inputs only): the best score of an alignment of q[0..qe] with t[0..te] that
+    starts at the origin and ends in the cell (qe, te) -- an upper bound for any path the banded walk can report, reached
+    when the band is wider than the sequences."""
+    NEG = -10 ** 9
+    a, b, go, ge = P.match, P.mismatch, P.gap_open, P.gap_extend
+    n, m = qe + 1, te + 1
+    H = [[NEG] * (m + 1) for _ in range(n + 1)]
+    E = [[NEG] * (m + 1) for _ in range(n + 1)]
+    F = [[NEG] * (m + 1) for _ in range(n + 1)]
+    H[0][0] = 0
+    for j in range(1, m + 1):
+        E[0][j] = H[0][j] = -(go + ge * j)
+    for i in range(1, n + 1):
+        F[i][0] = H[i][0] = -(go + ge * i)
+        for j in range(1, m + 1):
+            x, y = q[i - 1] & 15, t[j - 1] & 15
+            s = -1 if (x == 14 or y == 14) else (a if x == y else -b)
+            E[i][j] = max(E[i][j - 1] - ge, H[i][j - 1] - go - ge)
+            F[i][j] = max(F[i - 1][j] - ge, H[i - 1][j] - go - ge)
+            H[i][j] = max(H[i - 1][j - 1] + s, E[i][j], F[i][j])
+    return H[n][m]
+
+
+def test_traceback_paths_rescore_to_the_reported_score():
+    """agatha_model_traceback (cigar / n_cigar_ops are declared and never filled by the reference,
+    gasal.h:91-92, so there is no reference vector for them): scores and end cells equal the scoring model's, every path
+    re-scored from the sequences alone gives the reported score and uses query_end + 1 / target_end + 1 bases, long runs
+    are split at 63, and with a band wider than the sequences the path is optimal among all alignments ending in that cell."""
+    rng = np.random.default_rng(11)
+    total = nopath = 0
+    for w, z, n, L in ((751, 400, 30, 2500), (16, 400, 150, 300), (3, -1, 300, 60), (100, 50, 150, 800), (0, 400, 50, 40)):
+        P = O.make_params(w=w, z=z)
+        qs, ts = [], []
+        for k in range(n):
+            ln = int(rng.integers(1, L))
+            q = synth.random_seq(rng, ln)
+            t = synth.mutate(rng, q, 0.05, 0.04, 0.04)
+            if k % 7 == 0:
+                q = q.copy(); q[rng.integers(0, ln)] = ord('N')
+            qs.append(bytes(q)); ts.append(bytes(t))
+        s, qe, te, cig = O.traceback_pairs(qs, ts, P, threads=4)
+        s2, qe2, te2 = O.align_pairs(qs, ts, P, wide=True, model=O.MODEL_SLICES, threads=4)
+        assert (s == s2).all() and (qe == qe2).all() and (te == te2).all()
+        for k in range(n):
+            total += 1
+            if cig[k] is None:
+                nopath += 1
+                continue
+            if s[k] <= 0:
+                assert cig[k] == b""
+                continue
+            assert all(1 <= (b >> 2) <= 63 for b in cig[k])
+            assert O.cigar_rescore(cig[k], qs[k], ts[k], P) == (s[k], qe[k] + 1, te[k] + 1)
+    assert nopath <= total // 100          # only scores that came through a skipped band-edge cell have no path
+    # a 200-base identity: 63 + 63 + 63 + 11 matches
+    s, qe, te, cig = O.traceback_pairs([b"ACGTTGCA" * 25], [b"ACGTTGCA" * 25], O.make_params())
+    assert cig[0] == bytes([63 << 2, 63 << 2, 63 << 2, 11 << 2]) and s[0] == 400
+    # optimality inside a band that holds the whole matrix
+    P = O.make_params(w=400, z=-1)
+    qs, ts = [], []
+    for k in range(40):
+        q = synth.random_seq(rng, int(rng.integers(5, 70)))
+        qs.append(bytes(q)); ts.append(bytes(synth.mutate(rng, q, 0.1, 0.08, 0.08)))
+    s, qe, te, cig = O.traceback_pairs(qs, ts, P, threads=4)
+    for k in range(40):
+        if s[k] > 0:
+            assert _full_dp_best_path_score(qs[k], ts[k], P, int(qe[k]), int(te[k])) == s[k]
