@@ -5,8 +5,8 @@
 //   * the int32 compare kernel of align_body.inc with TB = true: the same schedule, band, tie-breaks and z-drop as the
 //     scoring pass (it IS the scoring kernel), which additionally stores a 4-bit code per computed cell -- 32 bytes per
 //     8x8 block, written once, never re-read by the pass: a pure HBM write stream of 0.5 byte per cell;
-//   * backtrace_kernel: one thread per pair walks the codes from the end cell to the origin (a chain of dependent
-//     loads, Q + R long at most; the pairs of a batch run side by side) and writes the path as GASAL2-style bytes.
+//   * backtrace_kernel: one wave per pair (lane 0) walks the codes from the end cell to the origin (a chain of dependent
+//     loads, one per 8x8 block on the path; the pairs of a batch run side by side) and writes the path as GASAL2-style bytes.
 // The CPU statement of both is oracle/agatha_oracle.c: agatha_model_traceback.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -73,11 +73,14 @@ hipError_t launch_align_tb(const AlignLaunch& L, int window_blocks, hipStream_t 
 // Output bytes: (count << 2) | op, op 0 = match, 1 = mismatch, 2 = D, 3 = I, count <= 63, longer runs split greedily from
 // the start; first byte = first column of the alignment.  A pair with score 0 has an empty alignment: 0 bytes.
 // ---------------------------------------------------------------------------------------------------
+// One WAVE per pair, lane 0 walking: with one pair per lane the 64 walks of a wave are in different states and blocks all
+// the time, so every iteration of every lane paid for every branch and for some lane's load (24 ms for 2 000 pairs of
+// 10 kb); a lone lane pays only for its own path, and the chip holds thousands of such waves.
 __global__ void __launch_bounds__(64)
 backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* __restrict__ n_ops)
 {
-    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= L.n) return;
+    const int pair = blockIdx.x;
+    if (threadIdx.x != 0 || pair >= L.n) return;
     const int score = L.score[pair];
     const int Q = (int)L.qlens[pair], R = (int)L.tlens[pair];
     if (score == INT_MIN) { n_ops[pair] = 0xFFFFFFFFu; return; }
@@ -90,19 +93,40 @@ backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* _
     const int w = L.p.band_width, sw = L.p.slice_width, W = (w + 7) >> 3;
     const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
 
+    // The walk is a chain of dependent loads; a path stays inside one 8x8 block for about eight cells, so the block's eight
+    // code words and the two sequence words are kept in registers and re-read only when the walk enters another block.
+    int cq = -1, cr = -1;                      // block whose code words are held (cw all zero: the pass never computed it)
+    uint32_t cw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int wqi = -1, wti = -1;
+    uint32_t wq = 0u, wt = 0u;
     // code of cell (i, j), 0 if the scoring pass never computed it
     auto code_of = [&](int i, int j) -> uint32_t {
-        const int q = i >> 3, r = j >> 3, step = q + r;
-        const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
-        const int i0 = (step / sw) * sw;                                  // first step of the slice (agatha_kernel.h:183-187)
-        const int ss = imax(imax(0, i0 - pql + 1), ((i0 * 8 + 8 - w) / 2) / 8);
-        const int se = imin(imin(prl - 1, i0 + sw - 1), (((i0 + sw - 1) * 8 + 7 + w) / 2) / 8);
-        if (r >= prl || q < cs || q > ce || r < ss || r > se) return 0u;
-        const uint32_t word = tb[((size_t)step * GS + (size_t)(r % GS)) * 8 + (i & 7)];
+        const int q = i >> 3, r = j >> 3;
+        if (q != cq || r != cr) {
+            cq = q; cr = r;
+            const int step = q + r;
+            const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
+            const int i0 = (step / sw) * sw;                              // first step of the slice (agatha_kernel.h:183-187)
+            const int ss = imax(imax(0, i0 - pql + 1), ((i0 * 8 + 8 - w) / 2) / 8);
+            const int se = imin(imin(prl - 1, i0 + sw - 1), (((i0 + sw - 1) * 8 + 7 + w) / 2) / 8);
+            if (r >= prl || q < cs || q > ce || r < ss || r > se) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) cw[m] = 0u;
+            } else {
+                const uint4* src = (const uint4*)(tb + ((size_t)step * GS + (size_t)(r % GS)) * 8);
+                const uint4 a = src[0], b = src[1];
+                cw[0] = a.x; cw[1] = a.y; cw[2] = a.z; cw[3] = a.w; cw[4] = b.x; cw[5] = b.y; cw[6] = b.z; cw[7] = b.w;
+            }
+        }
+        uint32_t word = cw[0];
+#pragma unroll
+        for (int m = 1; m < 8; m++) word = ((i & 7) == m) ? cw[m] : word;
         return (word >> (4 * (j & 7))) & 15u;
     };
     auto diag_op = [&](int i, int j) -> uint32_t {
-        const uint32_t a = (pq[i >> 3] >> (28 - 4 * (i & 7))) & 15u, b = (pt[j >> 3] >> (28 - 4 * (j & 7))) & 15u;
+        if ((i >> 3) != wqi) { wqi = i >> 3; wq = pq[wqi]; }
+        if ((j >> 3) != wti) { wti = j >> 3; wt = pt[wti]; }
+        const uint32_t a = (wq >> (28 - 4 * (i & 7))) & 15u, b = (wt >> (28 - 4 * (j & 7))) & 15u;
         return (a == b && a != N_VALUE) ? 0u : 1u;
     };
     uint32_t nb = 0, run_op = 4u, run = 0;
@@ -153,7 +177,7 @@ backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* _
 
 hipError_t launch_backtrace(const AlignLaunch& L, int group_slots, uint8_t* cigar, uint32_t* n_ops, hipStream_t st)
 {
-    hipLaunchKernelGGL(backtrace_kernel, dim3((L.n + 63) / 64), dim3(64), 0, st, L, group_slots, cigar, n_ops);
+    hipLaunchKernelGGL(backtrace_kernel, dim3(L.n), dim3(64), 0, st, L, group_slots, cigar, n_ops);
     return hipGetLastError();
 }
 

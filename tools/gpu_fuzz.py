@@ -17,7 +17,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 eng = agatha_amd.Engine(0)
 t_end = time.time() + budget
-trials = bad = 0
+trials = bad = tb_runs = 0
 while time.time() < t_end:
     w = int(rng.choice([16, 17, 30, 64, 100, 250, 500, 751, 760, 1000, 1500, int(rng.integers(16, 1700))]))
     m = int(rng.choice([1, 2, 3, 5, 16])); x = int(rng.choice([1, 3, 4, 6, 9, 32])); q = int(rng.choice([0, 1, 4, 6, 20, 64])); r = int(rng.choice([1, 2, 3, 16]))
@@ -56,5 +56,23 @@ while time.time() < t_end:
             i = diff[0]
             print("MISMATCH", mode, p, "n", len(ql), "pairs", diff[:6], "first: Q", int(ql[i]), "R", int(tl[i]),
                   "exp", [int(exp[j][i]) for j in range(3)], "got", [int(got[j][i]) for j in range(3)], "int16cfg", eng.last_int16_config(), flush=True)
+    if trials % 3 == 0:
+        # the traceback pass on the same batch: scores, ends and every path byte against the oracle's walk
+        es, eq, et, ecig, en = O.traceback_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), threads=16)
+        b = eng.batch(qb, tb, qo, to, ql, tl)
+        try:
+            b.upload(); b.pack()
+            gs, gq, gt, gc = b.align_traceback(agatha_amd.Scores.make(**p))
+        finally:
+            b.free()
+        off = qo.astype(np.int64) + to.astype(np.int64)
+        diff = [i for i in range(len(ql)) if (int(gs[i]), int(gq[i]), int(gt[i])) != (int(es[i]), int(eq[i]), int(et[i])) or
+                gc[i] != (None if en[i] < 0 else ecig[off[i]:off[i] + en[i]].tobytes())]
+        tb_runs += 1
+        if diff:
+            bad += 1
+            i = diff[0]
+            print("TRACEBACK MISMATCH", p, "n", len(ql), "pairs", diff[:6], "first: Q", int(ql[i]), "R", int(tl[i]), "exp", int(es[i]), int(eq[i]),
+                  int(et[i]), int(en[i]), "got", int(gs[i]), int(gq[i]), int(gt[i]), None if gc[i] is None else len(gc[i]), flush=True)
     trials += 1
-print("fuzz trials", trials, "mismatching runs", bad)
+print("fuzz trials", trials, "(traceback on", tb_runs, "of them) mismatching runs", bad)
