@@ -97,3 +97,47 @@ def test_broken_pairs_and_other_scorings(eng):
         got = _traceback(eng, qs, ts, **p)
         _check(qs, ts, got, **p)
     assert got[3][1] in (b"", None) or got[0][1] > 0
+
+
+def test_length_hints_that_are_too_small_are_refused_per_pair(eng):
+    """The code area is sized from the length hints: a pair longer than the hints must not write past its area -- it gets
+    AGATHA_AMD_BAD_RESULT / AGATHA_AMD_NO_PATH and its neighbours are untouched."""
+    import ctypes as C
+    import agatha_amd
+    from agatha_amd.engine import _DevBuf, _chk
+    qs, ts = _pairs(91, 24, 300, 600, n_every=0)
+    long_q = bytes(synth.random_seq(np.random.default_rng(3), 3000))
+    qs[7], ts[7] = long_q, long_q
+    p = dict(w=64, z=400)
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    lib = eng.lib
+    sc = agatha_amd.Scores.make(**p)
+    try:
+        b.upload(); b.pack()
+        hint = 640                                              # true for every pair but number 7
+        per = lib.agatha_amd_traceback_pair_bytes(hint, hint, C.byref(sc))
+        scratch, cig, nops = _DevBuf(lib, per * 24), _DevBuf(lib, b.qbytes + b.tbytes + 16), _DevBuf(lib, 4 * 24)
+        m = b.d_meta
+        _chk(lib, lib.agatha_amd_align_traceback(eng.stream, b.d_pk_q.ptr, b.d_pk_t.ptr, m[2].ptr, m[3].ptr, m[0].ptr, m[1].ptr, 24,
+                                                 hint, hint, C.byref(sc), b.d_res[0].ptr, b.d_res[1].ptr, b.d_res[2].ptr, cig.ptr,
+                                                 nops.ptr, b.d_ws.ptr, b.ws_bytes, scratch.ptr, per * 24))
+        h_n = np.zeros(24, np.uint32)
+        h_c = np.zeros(b.qbytes + b.tbytes, np.uint8)
+        _chk(lib, lib.agatha_amd_memcpy_d2h_async(eng.stream, h_n.ctypes.data, nops.ptr, 96))
+        _chk(lib, lib.agatha_amd_memcpy_d2h_async(eng.stream, h_c.ctypes.data, cig.ptr, h_c.nbytes))
+        b.download()
+        eng.synchronize()
+        res = b.res_host.copy()
+        for d in (scratch, cig, nops):
+            d.free()
+    finally:
+        b.free()
+    assert res[0][7] == np.iinfo(np.int32).min and h_n[7] == 0xFFFFFFFF
+    s, qe, te, cigs = O.traceback_pairs(qs, ts, O.make_params(**p), threads=4)
+    off = qo.astype(np.int64) + to.astype(np.int64)
+    for k in range(24):
+        if k != 7:
+            assert (res[0][k], res[1][k], res[2][k]) == (s[k], qe[k], te[k])
+            assert h_c[off[k]:off[k] + h_n[k]].tobytes() == cigs[k]
