@@ -24,7 +24,7 @@ static hipError_t launch_tb_t(const AlignLaunch& L, hipStream_t st)
 {
     const int groups_per_block = (256 / 64) * (64 / G);
     int blocks = (L.n + groups_per_block - 1) / groups_per_block;
-    int max_blocks = L.num_cus;            // the recording variant needs the whole register file: one workgroup per CU
+    int max_blocks = L.num_cus * (S <= 3 ? 2 : 1);
     if (L.max_blocks_override > 0) max_blocks = L.max_blocks_override;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
