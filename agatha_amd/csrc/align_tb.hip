@@ -5,8 +5,8 @@
 //   * the int32 compare kernel of align_body.inc with TB = true: the same schedule, band, tie-breaks and z-drop as the
 //     scoring pass (it IS the scoring kernel), which additionally stores a 4-bit code per computed cell -- 32 bytes per
 //     8x8 block, written once, never re-read by the pass: a pure HBM write stream of 0.5 byte per cell;
-//   * backtrace_kernel: one wave per pair (lane 0) walks the codes from the end cell to the origin (a chain of dependent
-//     loads, one per 8x8 block on the path; the pairs of a batch run side by side) and writes the path as GASAL2-style bytes.
+//   * backtrace_kernel: one wave per pair walks the codes from the end cell to the origin as a scalar program (a chain of
+//     dependent loads, one per 8x8 block on the path; the pairs of a batch run side by side) and writes GASAL2-style bytes.
 // The CPU statement of both is oracle/agatha_oracle.c: agatha_model_traceback.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -73,19 +73,26 @@ hipError_t launch_align_tb(const AlignLaunch& L, int window_blocks, hipStream_t 
 // Output bytes: (count << 2) | op, op 0 = match, 1 = mismatch, 2 = D, 3 = I, count <= 63, longer runs split greedily from
 // the start; first byte = first column of the alignment.  A pair with score 0 has an empty alignment: 0 bytes.
 // ---------------------------------------------------------------------------------------------------
-// One WAVE per pair, lane 0 walking: with one pair per lane the 64 walks of a wave are in different states and blocks all
-// the time, so every iteration of every lane paid for every branch and for some lane's load (24 ms for 2 000 pairs of
-// 10 kb); a lone lane pays only for its own path, and the chip holds thousands of such waves.
+// One WAVE per pair, and the walk is SCALAR: every quantity of it (cell, state, run length) is the same in all 64 lanes, so
+// it lives in SGPRs and costs scalar instructions; the lanes are only used as storage and memory ports -- lanes 0..7 hold the
+// eight code words of the block the path is in (one coalesced 32-byte load when the path enters a block, v_readlane to pick
+// the row), lane 0 writes the bytes, all lanes turn the byte string round at the end.  (History: one pair per LANE, 24 ms for
+// 2 000 pairs of 10 kb -- the 64 walks of a wave are never in the same state or block, so every lane paid for every branch
+// and every load; one pair per wave with lane 0 walking in vector registers, 9 ms.)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 __global__ void __launch_bounds__(64)
 backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* __restrict__ n_ops)
 {
     const int pair = blockIdx.x;
-    if (threadIdx.x != 0 || pair >= L.n) return;
-    const int score = L.score[pair];
-    const int Q = (int)L.qlens[pair], R = (int)L.tlens[pair];
-    if (score == INT_MIN) { n_ops[pair] = 0xFFFFFFFFu; return; }
-    if (score <= 0 || Q <= 0 || R <= 0) { n_ops[pair] = 0u; return; }
-    const uint32_t qo = L.qoffs[pair], to = L.toffs[pair];
+    const int lane = threadIdx.x;
+    if (pair >= L.n) return;
+    const int score = uni(L.score[pair]);
+    const int Q = uni((int)L.qlens[pair]), R = uni((int)L.tlens[pair]);
+    if (score == INT_MIN) { if (lane == 0) n_ops[pair] = 0xFFFFFFFFu; return; }
+    if (score <= 0 || Q <= 0 || R <= 0) { if (lane == 0) n_ops[pair] = 0u; return; }
+    const uint32_t qo = uniu(L.qoffs[pair]), to = uniu(L.toffs[pair]);
     const uint32_t* pq = L.packed_q + (qo >> 3);
     const uint32_t* pt = L.packed_t + (to >> 3);
     const uint32_t* tb = L.tb_codes + (size_t)pair * L.tb_pair_words;
@@ -93,10 +100,8 @@ backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* _
     const int w = L.p.band_width, sw = L.p.slice_width, W = (w + 7) >> 3;
     const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
 
-    // The walk is a chain of dependent loads; a path stays inside one 8x8 block for about eight cells, so the block's eight
-    // code words and the two sequence words are kept in registers and re-read only when the walk enters another block.
-    int cq = -1, cr = -1;                      // block whose code words are held (cw all zero: the pass never computed it)
-    uint32_t cw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int cq = -1, cr = -1;                      // block whose code words the lanes hold (all zero: the pass never computed it)
+    uint32_t myw = 0u;                         // lane l < 8: code word of row l of that block
     int wqi = -1, wti = -1;
     uint32_t wq = 0u, wt = 0u;
     // code of cell (i, j), 0 if the scoring pass never computed it
@@ -109,34 +114,33 @@ backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* _
             const int i0 = (step / sw) * sw;                              // first step of the slice (agatha_kernel.h:183-187)
             const int ss = imax(imax(0, i0 - pql + 1), ((i0 * 8 + 8 - w) / 2) / 8);
             const int se = imin(imin(prl - 1, i0 + sw - 1), (((i0 + sw - 1) * 8 + 7 + w) / 2) / 8);
-            if (r >= prl || q < cs || q > ce || r < ss || r > se) {
-#pragma unroll
-                for (int m = 0; m < 8; m++) cw[m] = 0u;
-            } else {
-                const uint4* src = (const uint4*)(tb + ((size_t)step * GS + (size_t)(r % GS)) * 8);
-                const uint4 a = src[0], b = src[1];
-                cw[0] = a.x; cw[1] = a.y; cw[2] = a.z; cw[3] = a.w; cw[4] = b.x; cw[5] = b.y; cw[6] = b.z; cw[7] = b.w;
-            }
+            if (r >= prl || q < cs || q > ce || r < ss || r > se) myw = 0u;
+            else myw = tb[((size_t)step * GS + (size_t)(r % GS)) * 8 + (size_t)(lane & 7)];
         }
-        uint32_t word = cw[0];
-#pragma unroll
-        for (int m = 1; m < 8; m++) word = ((i & 7) == m) ? cw[m] : word;
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)myw, i & 7);
         return (word >> (4 * (j & 7))) & 15u;
     };
     auto diag_op = [&](int i, int j) -> uint32_t {
-        if ((i >> 3) != wqi) { wqi = i >> 3; wq = pq[wqi]; }
-        if ((j >> 3) != wti) { wti = j >> 3; wt = pt[wti]; }
+        if ((i >> 3) != wqi) { wqi = i >> 3; wq = uniu(pq[wqi]); }
+        if ((j >> 3) != wti) { wti = j >> 3; wt = uniu(pt[wti]); }
         const uint32_t a = (wq >> (28 - 4 * (i & 7))) & 15u, b = (wt >> (28 - 4 * (j & 7))) & 15u;
         return (a == b && a != N_VALUE) ? 0u : 1u;
     };
+    // Runs are produced end to start.  A run longer than 63 leaves as its remainder FIRST and its full bytes after it, so that
+    // the string turned round reads greedily from the start (63, 63, ..., remainder) like the oracle's.
     uint32_t nb = 0, run_op = 4u, run = 0;
+    auto flush = [&]() {
+        uint32_t rem = run % 63u, full = run / 63u;
+        if (rem) { if (lane == 0) out[nb] = (uint8_t)((rem << 2) | run_op); nb++; }
+        for (; full; full--) { if (lane == 0) out[nb] = (uint8_t)((63u << 2) | run_op); nb++; }
+    };
     auto emit = [&](uint32_t op) {
-        if (op == run_op && run < 63u) { run++; return; }
-        if (run) out[nb++] = (uint8_t)((run << 2) | run_op);
+        if (op == run_op) { run++; return; }
+        if (run) flush();
         run_op = op; run = 1;
     };
 
-    int i = L.qend[pair], j = L.tend[pair], state = 0;
+    int i = uni(L.qend[pair]), j = uni(L.tend[pair]), state = 0;
     bool bad = false;
     for (int guard = Q + R + 16; i >= 0 && j >= 0 && guard > 0; guard--) {
         uint32_t code = code_of(i, j);
@@ -159,20 +163,18 @@ backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* _
             if (!(code & 8u)) { emit(diag_op(i, j)); i--; j--; state = 0; }
         }
     }
-    if (bad || (i >= 0 && j >= 0)) { n_ops[pair] = 0xFFFFFFFFu; return; }
+    if (bad || (i >= 0 && j >= 0)) { if (lane == 0) n_ops[pair] = 0xFFFFFFFFu; return; }
     for (; i >= 0; i--) emit(3u);
     for (; j >= 0; j--) emit(2u);
-    if (run) out[nb++] = (uint8_t)((run << 2) | run_op);
-    // the bytes were produced end to start: turn them round, then move the short remainder of a split run behind its
-    // full bytes (greedy from the start, like the oracle)
-    for (uint32_t a = 0, b = nb - 1; a < b; a++, b--) { const uint8_t x = out[a]; out[a] = out[b]; out[b] = x; }
-    for (uint32_t a = 0; a < nb; ) {
-        uint32_t b = a;
-        while (b + 1 < nb && (out[b + 1] & 3u) == (out[a] & 3u)) b++;
-        if (b > a) { const uint8_t x = out[a]; out[a] = out[b]; out[b] = x; }
-        a = b + 1;
+    if (run) flush();
+    // turn the string round (lane 0's byte stores first, then all lanes swap)
+    __threadfence();
+    for (uint32_t a = (uint32_t)lane; 2u * a + 1u < nb; a += 64u) {
+        const uint32_t b = nb - 1u - a;
+        const uint8_t x = out[a], y = out[b];
+        out[a] = y; out[b] = x;
     }
-    n_ops[pair] = nb;
+    if (lane == 0) n_ops[pair] = nb;
 }
 
 hipError_t launch_backtrace(const AlignLaunch& L, int group_slots, uint8_t* cigar, uint32_t* n_ops, hipStream_t st)
