@@ -20,7 +20,7 @@ namespace agatha {
 #include "align_body.inc"
 
 template <int G, int S>
-static hipError_t launch_tb_t(const AlignLaunch& L, hipStream_t st)
+static hipError_t launch_tb_t(const AlignLaunch& L, int pass, hipStream_t st)
 {
     const int groups_per_block = (256 / 64) * (64 / G);
     int blocks = (L.n + groups_per_block - 1) / groups_per_block;
@@ -28,11 +28,11 @@ static hipError_t launch_tb_t(const AlignLaunch& L, hipStream_t st)
     if (L.max_blocks_override > 0) max_blocks = L.max_blocks_override;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((align_kernel<G, S, true, true>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p, -1, 0);
+    hipLaunchKernelGGL((align_kernel<G, S, true, true>), dim3(blocks), dim3(256), 0, st, L.self_dev, L.p, pass, 0);
     return hipGetLastError();
 }
 
-struct TbCfg { int G, S; hipError_t (*fn)(const AlignLaunch&, hipStream_t); };
+struct TbCfg { int G, S; hipError_t (*fn)(const AlignLaunch&, int, hipStream_t); };
 static const TbCfg kTbCfgs[] = {       // ascending G*S: the smallest one that holds the window is used
     {16, 3, launch_tb_t<16, 3>}, {32, 3, launch_tb_t<32, 3>}, {64, 3, launch_tb_t<64, 3>}, {64, 6, launch_tb_t<64, 6>},
 };
@@ -55,11 +55,61 @@ int tb_key_bits(int window_blocks)
     return k;
 }
 
-hipError_t launch_align_tb(const AlignLaunch& L, int window_blocks, hipStream_t st)
+hipError_t launch_align_tb(const AlignLaunch& L, int window_blocks, int pass, hipStream_t st)
 {
     const TbCfg* c = tb_cfg(window_blocks);
     if (!c || !L.force_cmp || !L.tb_codes) return hipErrorInvalidValue;
-    return c->fn(L, st);
+    return c->fn(L, pass, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The plan: every pair's code area is (row blocks + column blocks) * G*S * 8 words, from its TRUE lengths; the pairs are
+// packed into the area in input order, and when the next one does not fit the area is started over -- a new pass.  One
+// wave: 64 sizes per coalesced load, then a scalar walk over the 64 lanes (the running offset depends on every pair before).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+tb_plan_kernel(AlignLaunch L, int GS, unsigned long long cap_words, int max_passes, unsigned long long* __restrict__ off,
+               int* __restrict__ pass, int* __restrict__ plan)
+{
+    const int lane = threadIdx.x;
+    unsigned long long cur = 0ull;
+    int p = 0;
+    for (int base = 0; base < L.n; base += 64) {
+        const int k = base + lane;
+        unsigned long long size = 0ull;
+        if (k < L.n) {
+            const unsigned long long Q = L.qlens[k], R = L.tlens[k];
+            if (Q > 0 && R > 0) size = (((Q + 7) >> 3) + ((R + 7) >> 3)) * (unsigned long long)(GS * 8);
+        }
+        unsigned long long my_off = 0ull;
+        int my_pass = 0;
+        const int cnt = (L.n - base < 64) ? L.n - base : 64;
+        for (int l = 0; l < cnt; l++) {
+            const unsigned long long s = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(size >> 32), l) << 32) |
+                                         (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)size, l);
+            int ps;
+            unsigned long long os = 0ull;
+            if (s > cap_words) ps = -1;                       // does not fit even alone
+            else {
+                if (cur + s > cap_words) { p++; cur = 0ull; }
+                ps = p < max_passes ? p : -1;                 // (more passes than the host launches: the length hints were wrong)
+                os = cur; cur += s;
+            }
+            if (l == lane) { my_off = os; my_pass = ps; }
+        }
+        if (k < L.n) {
+            off[k] = my_off; pass[k] = my_pass;
+            if (my_pass < 0) { L.score[k] = INT_MIN; L.qend[k] = -1; L.tend[k] = -1; }       // AGATHA_AMD_BAD_RESULT
+        }
+    }
+    if (lane == 0) plan[0] = p + 1 < max_passes ? p + 1 : max_passes;
+}
+
+hipError_t launch_tb_plan(const AlignLaunch& L, int group_slots, unsigned long long cap_words, int max_passes,
+                          unsigned long long* off, int* pass, int* plan, hipStream_t st)
+{
+    hipLaunchKernelGGL(tb_plan_kernel, dim3(1), dim3(64), 0, st, L, group_slots, cap_words, max_passes, off, pass, plan);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -83,11 +133,16 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 __global__ void __launch_bounds__(64)
-backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* __restrict__ n_ops)
+backtrace_kernel(AlignLaunch L, int GS, int pass, uint8_t* __restrict__ cigar, uint32_t* __restrict__ n_ops)
 {
     const int pair = blockIdx.x;
     const int lane = threadIdx.x;
     if (pair >= L.n) return;
+    {
+        // this launch walks the pairs whose codes the pass just recorded (the first one also marks the pairs without codes)
+        const int pp = uni(L.tb_pass[pair]);
+        if (pp != pass && !(pass == 0 && pp < 0)) return;
+    }
     const int score = uni(L.score[pair]);
     const int Q = uni((int)L.qlens[pair]), R = uni((int)L.tlens[pair]);
     if (score == INT_MIN) { if (lane == 0) n_ops[pair] = 0xFFFFFFFFu; return; }
@@ -95,7 +150,7 @@ backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* _
     const uint32_t qo = uniu(L.qoffs[pair]), to = uniu(L.toffs[pair]);
     const uint32_t* pq = L.packed_q + (qo >> 3);
     const uint32_t* pt = L.packed_t + (to >> 3);
-    const uint32_t* tb = L.tb_codes + (size_t)pair * L.tb_pair_words;
+    const uint32_t* tb = L.tb_codes + L.tb_off[pair];
     uint8_t* out = cigar + (size_t)qo + (size_t)to;
     const int w = L.p.band_width, sw = L.p.slice_width, W = (w + 7) >> 3;
     const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
@@ -177,9 +232,9 @@ backtrace_kernel(AlignLaunch L, int GS, uint8_t* __restrict__ cigar, uint32_t* _
     if (lane == 0) n_ops[pair] = nb;
 }
 
-hipError_t launch_backtrace(const AlignLaunch& L, int group_slots, uint8_t* cigar, uint32_t* n_ops, hipStream_t st)
+hipError_t launch_backtrace(const AlignLaunch& L, int group_slots, int pass, uint8_t* cigar, uint32_t* n_ops, hipStream_t st)
 {
-    hipLaunchKernelGGL(backtrace_kernel, dim3(L.n), dim3(64), 0, st, L, group_slots, cigar, n_ops);
+    hipLaunchKernelGGL(backtrace_kernel, dim3(L.n), dim3(64), 0, st, L, group_slots, pass, cigar, n_ops);
     return hipGetLastError();
 }
 

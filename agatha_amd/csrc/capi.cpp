@@ -176,14 +176,20 @@ static long window_blocks(const agatha_amd_scores* sc, uint32_t max_query_len, u
     return std::max(window, 1L);
 }
 
-// tb_codes != nullptr: the traceback pass (every pair through the compare kernel, which also records the cell codes)
+// the traceback pass (every pair through the compare kernel, which also records the cell codes, then the walk)
+struct TracebackArgs {
+    void* scratch; size_t scratch_bytes;
+    uint8_t* cigar; uint32_t* n_ops;
+};
+static size_t tb_header_bytes(uint32_t n) { return round_up(8 * (size_t)n) + round_up(4 * (size_t)n) + kAlign; }
+
+// tb != nullptr: the traceback pass instead of the scoring kernels
 static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
                       const uint32_t* d_query_lens, const uint32_t* d_target_lens,
                       const uint32_t* d_query_offsets, const uint32_t* d_target_offsets,
                       uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
                       const agatha_amd_scores* sc, int32_t* d_aln_score, int32_t* d_query_batch_end,
-                      int32_t* d_target_batch_end, void* d_workspace, size_t workspace_bytes,
-                      uint32_t* tb_codes, size_t tb_pair_words, agatha::AlignLaunch* L_out)
+                      int32_t* d_target_batch_end, void* d_workspace, size_t workspace_bytes, const TracebackArgs* tb)
 {
     if (!d_packed_query || !d_packed_target || !d_query_lens || !d_target_lens || !d_query_offsets ||
         !d_target_offsets || !sc || !d_aln_score || !d_query_batch_end || !d_target_batch_end || !d_workspace)
@@ -197,7 +203,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     // scores are carried as H << K in int32: the largest possible score -- and, with z-drop off, the deepest negative one --
     // must stay below 2^(30-K).  With length hints the whole call is refused here; without them (0 = unknown) the device
     // checks every pair and writes AGATHA_AMD_BAD_RESULT for the ones that do not fit (exotic_kernel, kind 3).
-    const int Kbits = tb_codes ? agatha::tb_key_bits((int)window) : agatha::key_bits_for_window((int)window);
+    const int Kbits = tb ? agatha::tb_key_bits((int)window) : agatha::key_bits_for_window((int)window);
     if (Kbits < 0) return AGATHA_AMD_ERANGE;
     const long long score_limit = 1ll << (30 - Kbits);
     if (max_query_len || max_target_len) {
@@ -242,9 +248,29 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.exotic = exotic;
     L.kind_counts = queue + 12;
     L.score_limit = score_limit;
-    L.force_cmp = (tb_codes || sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
-    L.tb_codes = tb_codes; L.tb_pair_words = tb_pair_words;
+    L.force_cmp = (tb || sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
+    L.tb_codes = nullptr; L.tb_off = nullptr; L.tb_pass = nullptr; L.tb_plan = nullptr;
     HIPCHK(agatha::launch_exotic(L, st));
+    int tb_passes = 0, tb_gs = 0;
+    if (tb) {
+        // scratch = [word offset of every pair's codes | its pass | the plan | the code area]; the number of passes launched
+        // is the worst case (every pair as long as the hints): a pass the plan did not need returns at once, so that the
+        // call stays asynchronous
+        tb_gs = agatha::tb_group_slots((int)window);
+        const size_t pair_bytes = agatha_amd_traceback_pair_bytes(max_query_len, max_target_len, sc);
+        if (!tb_gs || !pair_bytes) return AGATHA_AMD_EBAND;
+        const size_t head = tb_header_bytes(n_alns);
+        if (tb->scratch_bytes < head + pair_bytes) return AGATHA_AMD_EWORKSPACE;
+        const size_t cap = (tb->scratch_bytes - head) & ~(size_t)255;
+        const size_t per_pass = cap / pair_bytes;
+        tb_passes = (int)std::min<size_t>(((size_t)n_alns + per_pass - 1) / per_pass, 1u << 20);
+        char* p = (char*)tb->scratch;
+        unsigned long long* off = (unsigned long long*)p;   p += round_up(8 * (size_t)n_alns);
+        int* pass = (int*)p;                                 p += round_up(4 * (size_t)n_alns);
+        int* plan = (int*)p;                                 p += kAlign;
+        L.tb_codes = (uint32_t*)p; L.tb_off = off; L.tb_pass = pass; L.tb_plan = plan;
+        HIPCHK(agatha::launch_tb_plan(L, tb_gs, (unsigned long long)(cap / 4), tb_passes, off, pass, plan, st));
+    }
     L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;
     L.mig_slot_dwords = 0;
     L.timeline = nullptr;
@@ -277,8 +303,14 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     }
     L.self_dev = rec;
     HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record, queue head reset, kernel choice; stream-ordered
-    if (L_out) *L_out = L;
-    if (tb_codes) { HIPCHK(agatha::launch_align_tb(L, (int)window, st)); return 0; }
+    if (tb) {
+        for (int pass = 0; pass < tb_passes; pass++) {
+            if (pass > 0) HIPCHK(agatha::launch_record(L, rec, st));       // queue heads back to 0
+            HIPCHK(agatha::launch_align_tb(L, (int)window, pass, st));
+            HIPCHK(agatha::launch_backtrace(L, tb_gs, pass, tb->cigar, tb->n_ops, st));
+        }
+        return 0;
+    }
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));
     HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st));
     if (g_ev1) HIPCHK(hipEventRecord(g_ev1, st));
@@ -294,7 +326,7 @@ int agatha_amd_align(void* stream, const uint32_t* d_packed_query, const uint32_
 {
     return align_impl(stream, d_packed_query, d_packed_target, d_query_lens, d_target_lens, d_query_offsets, d_target_offsets,
                       n_alns, max_query_len, max_target_len, sc, d_aln_score, d_query_batch_end, d_target_batch_end,
-                      d_workspace, workspace_bytes, nullptr, 0, nullptr);
+                      d_workspace, workspace_bytes, nullptr);
 }
 
 size_t agatha_amd_traceback_pair_bytes(uint32_t max_query_len, uint32_t max_target_len, const agatha_amd_scores* sc)
@@ -316,24 +348,20 @@ int agatha_amd_align_traceback(void* stream, const uint32_t* d_packed_query, con
                                void* d_workspace, size_t workspace_bytes, void* d_scratch, size_t scratch_bytes)
 {
     if (!d_cigar || !d_n_cigar_ops || !d_scratch || !sc || n_alns == 0) return AGATHA_AMD_EINVAL;
-    if (!max_query_len || !max_target_len) return AGATHA_AMD_EINVAL;        // the code area is sized from the hints
-    const size_t pair_bytes = agatha_amd_traceback_pair_bytes(max_query_len, max_target_len, sc);
-    if (!pair_bytes) return AGATHA_AMD_EBAND;
-    const size_t per_pass = scratch_bytes / pair_bytes;
-    if (!per_pass) return AGATHA_AMD_EWORKSPACE;
-    const int gs = agatha::tb_group_slots((int)window_blocks(sc, max_query_len, max_target_len));
-    for (uint32_t a = 0; a < n_alns; ) {
-        const uint32_t m = (uint32_t)std::min<size_t>(per_pass, n_alns - a);
-        agatha::AlignLaunch L;
-        const int rc = align_impl(stream, d_packed_query, d_packed_target, d_query_lens + a, d_target_lens + a,
-                                  d_query_offsets + a, d_target_offsets + a, m, max_query_len, max_target_len, sc,
-                                  d_aln_score + a, d_query_batch_end + a, d_target_batch_end + a, d_workspace, workspace_bytes,
-                                  (uint32_t*)d_scratch, pair_bytes / 4, &L);
-        if (rc != 0) return rc;
-        HIPCHK(agatha::launch_backtrace(L, gs, d_cigar, d_n_cigar_ops + a, (hipStream_t)stream));
-        a += m;
-    }
-    return 0;
+    if (!max_query_len || !max_target_len) return AGATHA_AMD_EINVAL;        // they bound the number of passes
+    TracebackArgs tb = {d_scratch, scratch_bytes, d_cigar, d_n_cigar_ops};
+    return align_impl(stream, d_packed_query, d_packed_target, d_query_lens, d_target_lens, d_query_offsets, d_target_offsets,
+                      n_alns, max_query_len, max_target_len, sc, d_aln_score, d_query_batch_end, d_target_batch_end,
+                      d_workspace, workspace_bytes, &tb);
+}
+
+size_t agatha_amd_traceback_scratch_bytes(uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
+                                          const agatha_amd_scores* sc, uint32_t pairs_per_pass)
+{
+    const size_t per = agatha_amd_traceback_pair_bytes(max_query_len, max_target_len, sc);
+    if (!per || !n_alns) return 0;
+    if (pairs_per_pass == 0 || pairs_per_pass > n_alns) pairs_per_pass = n_alns;
+    return tb_header_bytes(n_alns) + 256 + per * (size_t)pairs_per_pass;
 }
 
 int agatha_amd_set_debug_option(const char* name, int value)

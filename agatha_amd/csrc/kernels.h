@@ -53,9 +53,12 @@ struct AlignLaunch {
     int prio_duty;                 // of every 16 slices, the wave in slot 0 of its SIMD is the favoured one in this many
     unsigned int mig_test_delay_ticks;   // tests: odd lane groups sleep this long before they start (forces the take-over)
     // ---- traceback pass (align_tb.hip): the compare kernel also records a 4-bit code per computed cell ----
-    uint32_t* tb_codes;            // device: tb_pair_words words per pair of the launch; 8 words (one per block row, a nibble
-                                   // per column) for (step, column block mod G*S) at ((step * G*S) + slot) * 8
-    size_t tb_pair_words;
+    uint32_t* tb_codes;            // device: the code area; pair k's words start at tb_off[k]: 8 words (one per block row, a
+                                   // nibble per column) for (step, column block mod G*S) at ((step * G*S) + slot) * 8
+    const unsigned long long* tb_off;   // device: word offset of each pair's codes inside its pass (tb_plan_kernel)
+    const int* tb_pass;            // device: the pass a pair belongs to (the code area is reused pass after pass); -1 = its codes
+                                   // do not fit the area at all (AGATHA_AMD_BAD_RESULT)
+    const int* tb_plan;            // device: [0] number of passes
 };
 
 // states of a boundary (the pair whose steps are split between lane groups b - 1 and b)
@@ -103,12 +106,16 @@ hipError_t launch_starts(const int32_t* qend, const int32_t* tend, const int32_t
                          int32_t* tstart, uint32_t n, hipStream_t st);
 // Traceback pass (align_tb.hip).  tb_group_slots: G*S of the shape it uses for this window (0: band too wide);
 // tb_key_bits: the K of that shape (score range check); launch_align_tb: the compare kernel with code recording, for every
-// pair of the launch (L.force_cmp must be 1, L.tb_codes set); launch_backtrace: one thread per pair walks the codes from
-// (qend, tend) to the origin and writes GASAL2-style bytes at cigar + qoffs[pair] + toffs[pair].
+// pair of the given pass (L.force_cmp must be 1, L.tb_codes set); launch_backtrace: one wave per pair of that pass walks
+// the codes from (qend, tend) to the origin and writes GASAL2-style bytes at cigar + qoffs[pair] + toffs[pair].
 int tb_group_slots(int window_blocks);
 int tb_key_bits(int window_blocks);
-hipError_t launch_align_tb(const AlignLaunch& L, int window_blocks, hipStream_t st);
-hipError_t launch_backtrace(const AlignLaunch& L, int group_slots, uint8_t* cigar, uint32_t* n_ops, hipStream_t st);
+// launch_tb_plan: sizes every pair's code area from its true lengths and packs the pairs, in input order, into passes over
+// cap_words words, at most max_passes of them (off / pass / plan as in AlignLaunch; pairs that do not fit get AGATHA_AMD_BAD_RESULT).
+hipError_t launch_tb_plan(const AlignLaunch& L, int group_slots, unsigned long long cap_words, int max_passes,
+                          unsigned long long* off, int* pass, int* plan, hipStream_t st);
+hipError_t launch_align_tb(const AlignLaunch& L, int window_blocks, int pass, hipStream_t st);
+hipError_t launch_backtrace(const AlignLaunch& L, int group_slots, int pass, uint8_t* cigar, uint32_t* n_ops, hipStream_t st);
 hipError_t launch_pack(const uint8_t* unpacked, uint32_t nbytes, uint32_t* packed, hipStream_t st);
 
 }  // namespace agatha

@@ -77,6 +77,8 @@ def load_library():
         [vp, C.c_size_t, vp, C.c_size_t]
     lib.agatha_amd_traceback_pair_bytes.restype = C.c_size_t
     lib.agatha_amd_traceback_pair_bytes.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Scores)]
+    lib.agatha_amd_traceback_scratch_bytes.restype = C.c_size_t
+    lib.agatha_amd_traceback_scratch_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Scores), C.c_uint32]
     lib.agatha_amd_align_traceback.argtypes = [vp, u32p, u32p, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.POINTER(Scores), i32p, i32p, i32p, vp, u32p, vp, C.c_size_t, vp, C.c_size_t]
     lib.agatha_amd_set_kernel_events.argtypes = [vp, vp]
@@ -112,6 +114,7 @@ EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack", "agatha_amd_pack_host",
     "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_starts_scratch_bytes", "agatha_amd_align_starts", "agatha_amd_traceback_pair_bytes",
+    "agatha_amd_traceback_scratch_bytes",
     "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
@@ -309,8 +312,9 @@ class DeviceBatch:
         per = lib.agatha_amd_traceback_pair_bytes(self.max_qlen, self.max_tlen, C.byref(scores))
         if per == 0:
             raise AgathaError("traceback: band too wide or empty batch")
-        if scratch_bytes is None:
-            scratch_bytes = min(per * self.n, max(per, 8 << 30))
+        if scratch_bytes is None:        # the whole batch in one pass, or passes of about 8 GiB
+            ppp = max(1, min(self.n, (8 << 30) // per))
+            scratch_bytes = lib.agatha_amd_traceback_scratch_bytes(self.n, self.max_qlen, self.max_tlen, C.byref(scores), ppp)
         scratch = _DevBuf(lib, scratch_bytes)
         cig = _DevBuf(lib, self.qbytes + self.tbytes + 16)
         nops = _DevBuf(lib, 4 * self.n)

@@ -465,7 +465,8 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
             exit(EXIT_FAILURE);
         }
         // the whole batch in one pass if that takes at most 16 GiB, otherwise in passes of 16 GiB
-        const size_t want = std::max(per, std::min(per * (size_t)actual_n_alns, (size_t)16 << 30));
+        const uint32_t ppp = (uint32_t)std::max<size_t>(1, std::min<size_t>(actual_n_alns, ((size_t)16 << 30) / per));
+        const size_t want = agatha_amd_traceback_scratch_bytes(actual_n_alns, max_q, max_t, &sc, ppp);
         if (s->tb_scratch_bytes < want) {
             CHK(agatha_amd_stream_synchronize(s->str));
             dev_free(s->tb_scratch);

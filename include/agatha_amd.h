@@ -128,11 +128,20 @@ int agatha_amd_align_starts(void* stream, const uint32_t* d_packed_query, const 
  * d_n_cigar_ops[k] = 0 for an empty alignment (score 0), AGATHA_AMD_NO_PATH for a pair whose result is
  * AGATHA_AMD_BAD_RESULT or whose score came through a cell the reference's block-granular band skips (the stale-register
  * reads of agatha_kernel.h:33-35: such a score belongs to no alignment; rare, needs a path along the band edge).
- * max_query_len / max_target_len are REQUIRED here (non-zero, true upper bounds): they size the code area.
- * d_scratch: any multiple (>= 1) of agatha_amd_traceback_pair_bytes() -- the batch is processed in passes of
- * scratch_bytes / pair_bytes pairs, so a small scratch costs launches, not correctness.  d_workspace as for agatha_amd_align. */
+ * d_scratch: agatha_amd_traceback_scratch_bytes(n_alns, max lens, scores, pairs_per_pass) of device memory: 16 bytes per pair
+ * + the code area.  Every pair's codes take (row blocks + column blocks) x 32 bytes x the lane-group size, from its TRUE
+ * lengths (agatha_amd_traceback_pair_bytes() is that for the longest possible pair: 8.6 MB for 10 kb x 10 kb at band 751);
+ * the device packs the pairs into the area in input order and starts it over when the next pair does not fit, so a small
+ * scratch (pairs_per_pass < n_alns; at least 1) costs passes, not correctness, and a batch of mixed lengths needs far fewer
+ * passes than its longest pair suggests.  max_query_len / max_target_len are REQUIRED here (non-zero, true upper bounds):
+ * the host launches the number of passes they imply without waiting for the device's plan (passes the plan does not need
+ * return at once); should a pair be longer than the hints, the pairs left over get AGATHA_AMD_BAD_RESULT / AGATHA_AMD_NO_PATH,
+ * as does a pair whose codes do not fit the area even alone.  d_workspace as for agatha_amd_align. */
 #define AGATHA_AMD_NO_PATH 0xFFFFFFFFu
 size_t agatha_amd_traceback_pair_bytes(uint32_t max_query_len, uint32_t max_target_len, const agatha_amd_scores* scores);
+/* pairs_per_pass: 0 = the whole batch in one pass (for pairs as long as the hints) */
+size_t agatha_amd_traceback_scratch_bytes(uint32_t n_alns, uint32_t max_query_len, uint32_t max_target_len,
+                                          const agatha_amd_scores* scores, uint32_t pairs_per_pass);
 int agatha_amd_align_traceback(void* stream,
                                const uint32_t* d_packed_query, const uint32_t* d_packed_target,
                                const uint32_t* d_query_lens, const uint32_t* d_target_lens,

@@ -70,15 +70,15 @@ def test_paths_match_oracle(eng, w, z, lo, hi, n):
 
 
 def test_paths_in_several_passes(eng):
-    """A scratch area that holds 5 pairs: the batch goes through in passes and nothing changes."""
+    """A scratch area that holds 5 pairs of the longest kind: the batch goes through in passes and nothing changes."""
     import agatha_amd
     qs, ts = _pairs(77, 64, 200, 1500)
     p = dict(w=64, z=400)
     lib = eng.lib
     import ctypes as C
-    per = lib.agatha_amd_traceback_pair_bytes(max(map(len, qs)), max(map(len, ts)), C.byref(agatha_amd.Scores.make(**p)))
+    small = lib.agatha_amd_traceback_scratch_bytes(64, max(map(len, qs)), max(map(len, ts)), C.byref(agatha_amd.Scores.make(**p)), 5)
     whole = _traceback(eng, qs, ts, **p)
-    parts = _traceback(eng, qs, ts, scratch_bytes=5 * per, **p)
+    parts = _traceback(eng, qs, ts, scratch_bytes=small, **p)
     assert all((a == b).all() for a, b in zip(whole[:3], parts[:3])) and whole[3] == parts[3]
     _check(qs, ts, parts, **p)
 
@@ -99,14 +99,15 @@ def test_broken_pairs_and_other_scorings(eng):
     assert got[3][1] in (b"", None) or got[0][1] > 0
 
 
-def test_length_hints_that_are_too_small_are_refused_per_pair(eng):
-    """The code area is sized from the length hints: a pair longer than the hints must not write past its area -- it gets
-    AGATHA_AMD_BAD_RESULT / AGATHA_AMD_NO_PATH and its neighbours are untouched."""
+def test_length_hints_that_are_too_small_cost_results_not_memory(eng):
+    """Code areas are sized from the TRUE lengths, the number of passes from the hints: with a pair much longer than the hints
+    the passes run out and the pairs left over get AGATHA_AMD_BAD_RESULT / AGATHA_AMD_NO_PATH -- every other pair is exact,
+    nothing is written outside the scratch."""
     import ctypes as C
     import agatha_amd
     from agatha_amd.engine import _DevBuf, _chk
     qs, ts = _pairs(91, 24, 300, 600, n_every=0)
-    long_q = bytes(synth.random_seq(np.random.default_rng(3), 3000))
+    long_q = bytes(synth.random_seq(np.random.default_rng(3), 12000))
     qs[7], ts[7] = long_q, long_q
     p = dict(w=64, z=400)
     qb, qo, ql = O.make_batch(qs)
@@ -117,16 +118,21 @@ def test_length_hints_that_are_too_small_are_refused_per_pair(eng):
     try:
         b.upload(); b.pack()
         hint = 640                                              # true for every pair but number 7
-        per = lib.agatha_amd_traceback_pair_bytes(hint, hint, C.byref(sc))
-        scratch, cig, nops = _DevBuf(lib, per * 24), _DevBuf(lib, b.qbytes + b.tbytes + 16), _DevBuf(lib, 4 * 24)
+        nbytes = lib.agatha_amd_traceback_scratch_bytes(24, hint, hint, C.byref(sc), 0)
+        guard = 1 << 20                                         # canary behind the scratch
+        scratch, cig, nops = _DevBuf(lib, nbytes + guard), _DevBuf(lib, b.qbytes + b.tbytes + 16), _DevBuf(lib, 4 * 24)
+        canary = np.full(guard, 0xA5, np.uint8)
+        _chk(lib, lib.agatha_amd_memcpy_h2d_async(eng.stream, scratch.ptr + nbytes, canary.ctypes.data, guard))
         m = b.d_meta
         _chk(lib, lib.agatha_amd_align_traceback(eng.stream, b.d_pk_q.ptr, b.d_pk_t.ptr, m[2].ptr, m[3].ptr, m[0].ptr, m[1].ptr, 24,
                                                  hint, hint, C.byref(sc), b.d_res[0].ptr, b.d_res[1].ptr, b.d_res[2].ptr, cig.ptr,
-                                                 nops.ptr, b.d_ws.ptr, b.ws_bytes, scratch.ptr, per * 24))
+                                                 nops.ptr, b.d_ws.ptr, b.ws_bytes, scratch.ptr, nbytes))
         h_n = np.zeros(24, np.uint32)
         h_c = np.zeros(b.qbytes + b.tbytes, np.uint8)
+        back = np.zeros(guard, np.uint8)
         _chk(lib, lib.agatha_amd_memcpy_d2h_async(eng.stream, h_n.ctypes.data, nops.ptr, 96))
         _chk(lib, lib.agatha_amd_memcpy_d2h_async(eng.stream, h_c.ctypes.data, cig.ptr, h_c.nbytes))
+        _chk(lib, lib.agatha_amd_memcpy_d2h_async(eng.stream, back.ctypes.data, scratch.ptr + nbytes, guard))
         b.download()
         eng.synchronize()
         res = b.res_host.copy()
@@ -134,10 +140,51 @@ def test_length_hints_that_are_too_small_are_refused_per_pair(eng):
             d.free()
     finally:
         b.free()
-    assert res[0][7] == np.iinfo(np.int32).min and h_n[7] == 0xFFFFFFFF
+    assert (back == 0xA5).all()
     s, qe, te, cigs = O.traceback_pairs(qs, ts, O.make_params(**p), threads=4)
     off = qo.astype(np.int64) + to.astype(np.int64)
+    refused = 0
     for k in range(24):
-        if k != 7:
+        if res[0][k] == np.iinfo(np.int32).min:
+            assert h_n[k] == 0xFFFFFFFF
+            refused += 1
+        else:
             assert (res[0][k], res[1][k], res[2][k]) == (s[k], qe[k], te[k])
             assert h_c[off[k]:off[k] + h_n[k]].tobytes() == cigs[k]
+    assert 1 <= refused <= 20
+
+
+def test_mixed_lengths_share_the_code_area(eng):
+    """One 6 kb pair among many short ones: sized by the longest pair the area would hold 4 pairs per pass; sized by the true
+    lengths everything fits one pass (checked through the plan the device leaves at the head of the scratch)."""
+    import ctypes as C
+    import agatha_amd
+    from agatha_amd.engine import _DevBuf, _chk
+    qs, ts = _pairs(17, 60, 100, 400)
+    big = synth.random_seq(np.random.default_rng(9), 6000)
+    qs[30], ts[30] = bytes(big), bytes(synth.mutate(np.random.default_rng(10), big, 0.03, 0.03, 0.03))
+    p = dict(w=100, z=400)
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    lib = eng.lib
+    sc = agatha_amd.Scores.make(**p)
+    try:
+        b.upload(); b.pack()
+        nbytes = lib.agatha_amd_traceback_scratch_bytes(60, b.max_qlen, b.max_tlen, C.byref(sc), 4)
+        got = b.align_traceback(sc, scratch_bytes=nbytes)           # (allocates its own scratch of that size)
+        scratch, cig, nops = _DevBuf(lib, nbytes), _DevBuf(lib, b.qbytes + b.tbytes + 16), _DevBuf(lib, 4 * 60)
+        m = b.d_meta
+        _chk(lib, lib.agatha_amd_align_traceback(eng.stream, b.d_pk_q.ptr, b.d_pk_t.ptr, m[2].ptr, m[3].ptr, m[0].ptr, m[1].ptr, 60,
+                                                 b.max_qlen, b.max_tlen, C.byref(sc), b.d_res[0].ptr, b.d_res[1].ptr, b.d_res[2].ptr,
+                                                 cig.ptr, nops.ptr, b.d_ws.ptr, b.ws_bytes, scratch.ptr, nbytes))
+        plan = np.zeros(1, np.int32)
+        head = ((8 * 60 + 255) // 256) * 256 + ((4 * 60 + 255) // 256) * 256
+        _chk(lib, lib.agatha_amd_memcpy_d2h_async(eng.stream, plan.ctypes.data, scratch.ptr + head, 4))
+        eng.synchronize()
+        for d in (scratch, cig, nops):
+            d.free()
+    finally:
+        b.free()
+    assert plan[0] == 1
+    _check(qs, ts, got, **p)

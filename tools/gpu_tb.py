@@ -23,7 +23,8 @@ b = eng.batch(qb, tb, qo, to, ql, tl)
 b.upload(); b.pack(); eng.synchronize()
 cells = W.nominal_cells_total(ql, tl, 751)
 per = lib.agatha_amd_traceback_pair_bytes(b.max_qlen, b.max_tlen, C.byref(sc))
-scratch = _DevBuf(lib, per * n)
+nbytes = lib.agatha_amd_traceback_scratch_bytes(n, b.max_qlen, b.max_tlen, C.byref(sc), 0)
+scratch = _DevBuf(lib, nbytes)
 cig = _DevBuf(lib, b.qbytes + b.tbytes + 16)
 nops = _DevBuf(lib, 4 * n)
 m = b.d_meta
@@ -32,7 +33,7 @@ m = b.d_meta
 def tb():
     _chk(lib, lib.agatha_amd_align_traceback(eng.stream, b.d_pk_q.ptr, b.d_pk_t.ptr, m[2].ptr, m[3].ptr, m[0].ptr, m[1].ptr, n,
                                              b.max_qlen, b.max_tlen, C.byref(sc), b.d_res[0].ptr, b.d_res[1].ptr, b.d_res[2].ptr,
-                                             cig.ptr, nops.ptr, b.d_ws.ptr, b.ws_bytes, scratch.ptr, per * n))
+                                             cig.ptr, nops.ptr, b.d_ws.ptr, b.ws_bytes, scratch.ptr, nbytes))
 
 
 for name, fn in (("align", lambda: b.align(sc)), ("align_traceback", tb)):
