@@ -188,3 +188,17 @@ def test_mixed_lengths_share_the_code_area(eng):
         b.free()
     assert plan[0] == 1
     _check(qs, ts, got, **p)
+
+
+def test_paths_match_the_golden_fixture(eng):
+    """The committed vectors of tests/golden/traceback_paths.json through the C-ABI."""
+    import json
+    import os
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "traceback_paths.json")))
+    for case in doc["cases"]:
+        qs = [q.encode() for q in case["queries"]]
+        ts = [t.encode() for t in case["targets"]]
+        got = _traceback(eng, qs, ts, **case["params"])
+        assert [int(v) for v in got[0]] == case["score"] and [int(v) for v in got[1]] == case["query_end"]
+        assert [int(v) for v in got[2]] == case["target_end"]
+        assert [None if c is None else c.hex() for c in got[3]] == case["bytes"]

@@ -300,3 +300,19 @@ def test_traceback_paths_rescore_to_the_reported_score():
     for k in range(40):
         if s[k] > 0:
             assert _full_dp_best_path_score(qs[k], ts[k], P, int(qe[k]), int(te[k])) == s[k]
+
+
+def test_traceback_golden_fixture():
+    """tests/golden/traceback_paths.json (generated by tests/golden/gen_traceback_golden.py) pins the definition of the paths."""
+    import json
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "traceback_paths.json")))
+    n = 0
+    for case in doc["cases"]:
+        qs = [q.encode() for q in case["queries"]]
+        ts = [t.encode() for t in case["targets"]]
+        s, qe, te, cig = O.traceback_pairs(qs, ts, O.make_params(**case["params"]))
+        assert [int(v) for v in s] == case["score"] and [int(v) for v in qe] == case["query_end"]
+        assert [int(v) for v in te] == case["target_end"]
+        assert [None if c is None else c.hex() for c in cig] == case["bytes"]
+        n += len(qs)
+    assert n == 48
