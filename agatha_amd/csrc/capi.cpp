@@ -263,7 +263,9 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         if (tb->scratch_bytes < head + pair_bytes) return AGATHA_AMD_EWORKSPACE;
         const size_t cap = (tb->scratch_bytes - head) & ~(size_t)255;
         const size_t per_pass = cap / pair_bytes;
-        tb_passes = (int)std::min<size_t>(((size_t)n_alns + per_pass - 1) / per_pass, 1u << 20);
+        const size_t need_passes = ((size_t)n_alns + per_pass - 1) / per_pass;
+        if (need_passes > 4096) return AGATHA_AMD_EWORKSPACE;          // (three launches per pass: give the call more scratch)
+        tb_passes = (int)need_passes;
         char* p = (char*)tb->scratch;
         unsigned long long* off = (unsigned long long*)p;   p += round_up(8 * (size_t)n_alns);
         int* pass = (int*)p;                                 p += round_up(4 * (size_t)n_alns);

@@ -132,8 +132,8 @@ int agatha_amd_align_starts(void* stream, const uint32_t* d_packed_query, const 
  * + the code area.  Every pair's codes take (row blocks + column blocks) x 32 bytes x the lane-group size, from its TRUE
  * lengths (agatha_amd_traceback_pair_bytes() is that for the longest possible pair: 8.6 MB for 10 kb x 10 kb at band 751);
  * the device packs the pairs into the area in input order and starts it over when the next pair does not fit, so a small
- * scratch (pairs_per_pass < n_alns; at least 1) costs passes, not correctness, and a batch of mixed lengths needs far fewer
- * passes than its longest pair suggests.  max_query_len / max_target_len are REQUIRED here (non-zero, true upper bounds):
+ * scratch (pairs_per_pass < n_alns; at least n_alns / 4096) costs passes, not correctness, and a batch of mixed lengths needs
+ * far fewer passes than its longest pair suggests.  max_query_len / max_target_len are REQUIRED here (non-zero, true upper bounds):
  * the host launches the number of passes they imply without waiting for the device's plan (passes the plan does not need
  * return at once); should a pair be longer than the hints, the pairs left over get AGATHA_AMD_BAD_RESULT / AGATHA_AMD_NO_PATH,
  * as does a pair whose codes do not fit the area even alone.  d_workspace as for agatha_amd_align. */
