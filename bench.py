@@ -247,6 +247,7 @@ def main():
     # (profiles/latest_pmc.json, written by tools/collate_profile.py); only quoted when it was taken on the kernel, the
     # workload and the schedule that just ran -- a stale file gives null, not a wrong number
     traffic = None
+    issued = conflicts = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
         same_kernel = pm.get("kernel", "").replace(" ", "").startswith(kname.rstrip(">").replace(" ", "") + ",") or \
@@ -254,6 +255,8 @@ def main():
         if pm.get("pairs") == a.pairs and pm.get("config", "C1") == a.config and same_kernel and not strong and \
                 bool(pm.get("preemptive_schedule", False)) == bool(sched[0]):
             traffic = float(pm["hbm_bytes_per_launch"])
+            issued = pm.get("valu_insts_per_launch")
+            conflicts = pm.get("lds_bank_conflict_cycles")
     except (OSError, ValueError, KeyError):
         pass
 
@@ -294,6 +297,8 @@ def main():
                               "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
                               "frac": cells * OPS_PER_CELL[kind] / kernel_ms / 1e9 / VALU_PEAK_TOPS,
                               "ops_per_cell": OPS_PER_CELL[kind],
+                              "issued_lane_ops_per_cell": (issued * 64.0 / cells) if issued else None,
+                              "lds_bank_conflict_cycles": conflicts,
                               "note": "lane-ops the recurrence itself needs per cell x cells/s over the measured VALU issue "
                                       "rate of the chip; the int16 kernel does two cells per packed lane-op"},
         }

@@ -38,6 +38,7 @@ if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
                "preemptive_schedule": bool(json.load(open(b)).get("config", {}).get("preemptive_schedule_rank0", {}).get("used", False)) if os.path.exists(b) else False,
                "hbm_bytes_per_launch": (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024,
                "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"],
+               "valu_insts_per_launch": m.get("SQ_INSTS_VALU"), "lds_bank_conflict_cycles": m.get("SQ_LDS_BANK_CONFLICT"),
                "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of a streamed read"},
               open(os.path.join(root, "profiles", "latest_pmc.json"), "w"), indent=1)
 print("dominant kernel:", short, "avg ms", float(dom["AverageNs"]) / 1e6)
