@@ -202,3 +202,10 @@ def test_paths_match_the_golden_fixture(eng):
         assert [int(v) for v in got[0]] == case["score"] and [int(v) for v in got[1]] == case["query_end"]
         assert [int(v) for v in got[2]] == case["target_end"]
         assert [None if c is None else c.hex() for c in got[3]] == case["bytes"]
+
+
+def test_single_pair_and_tiny_batches(eng):
+    for n in (1, 2, 3):
+        qs, ts = _pairs(200 + n, n, 1, 50)
+        got = _traceback(eng, qs, ts, w=8, z=-1)
+        _check(qs, ts, got, w=8, z=-1)
