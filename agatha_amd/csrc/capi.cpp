@@ -39,8 +39,9 @@ DebugOption g_opts[] = {
     {"prio_slice", "AGATHA_AMD_PRIO_SLICE", {-1}},     // > 0: SIMD partners alternate issue priority every 2^n ticks (10 ns each); -1: 2^15 on a static schedule, off otherwise; 0: off
     {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts)
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
+    {"fast_margin", "AGATHA_AMD_FAST_MARGIN", {16}},   // int16 kernel: value steps except in a pair's last n steps; 0: key steps only
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FAST_MARGIN, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -232,7 +233,8 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     uint32_t* timeline = (uint32_t*)ws;                      ws += round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords);
     uint32_t* mig_buf = (uint32_t*)ws;
 
-    // inside the 256-byte queue block: [0..3] queue heads, [8] step totals, [10] kernel choice, [12] pair-kind counters
+    // inside the 256-byte queue block: [0..3] queue heads, [8] step totals, [10] kernel choice, [12] pair-kind counters,
+    // [16..18] the schedule, [20..23] step statistics of the int16 kernel
     float* totals = (float*)(queue + 8);
     int* choice = (int*)(queue + 10);
     HIPCHK(hipMemsetAsync(queue, 0, kAlign, st));
@@ -247,6 +249,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.num_cus = num_cus();
     L.exotic = exotic;
     L.kind_counts = queue + 12;
+    L.step_stats = queue + 20;
     L.score_limit = score_limit;
     L.force_cmp = (tb || sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     L.tb_codes = nullptr; L.tb_off = nullptr; L.tb_pass = nullptr; L.tb_plan = nullptr;
@@ -286,6 +289,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     }
     L.mig_timeout_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TIMEOUT_US), 0);
     L.mig_test_delay_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TEST_DELAY_US), 0);
+    L.fast_margin = std::max(opt(OPT_FAST_MARGIN), 0);
     L.max_blocks_override = opt(OPT_MAX_BLOCKS);
     L.no_deal = opt(OPT_NO_DEAL) ? 1 : 0;
     // Candidates for the plain pairs: the packed-int16 kernel when the scores and the band allow it, the int32 kernel
@@ -453,6 +457,17 @@ int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_a
     hipError_t e = hipMemcpyAsync(out, ws + 16 * sizeof(unsigned int), 3 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "agatha_amd_schedule_info");
+    return 0;
+}
+
+int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[16])
+{
+    if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
+    const char* ws = (const char*)d_workspace;
+    ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets);
+    hipError_t e = hipMemcpyAsync(out, ws + 20 * sizeof(unsigned int), 16 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "agatha_amd_step_stats");
     return 0;
 }
 

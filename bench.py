@@ -238,6 +238,7 @@ def main():
 
     kinds = b.pair_kinds(stream)            # how the last step's pairs were routed between the kernels
     sched = b.schedule_info(stream)         # (static preemptive schedule used, steps per lane group, lane groups used)
+    sst = b.step_stats(stream)              # int16 kernel: (value wave-steps, key wave-steps, pairs started over, pairs started)
     kms = [eng.elapsed_ms(e0, e1) for e0, e1 in kev] if a.steps else [float("nan")]
     kernel_ms = float(np.mean(kms))
     G, S = eng.last_config()
@@ -282,6 +283,7 @@ def main():
                        "int32_fallback_kernel": f"agatha::align_kernel<{G},{S}>",
                        "pairs_plain_other_letters_int32_takeover_rank0": list(kinds),
                        "preemptive_schedule_rank0": {"used": sched[0], "steps_per_lane_group": sched[1], "lane_groups": sched[2]},
+                       "int16_steps_rank0": {"value_wave_steps": sst[0], "key_wave_steps": sst[1], "pairs_started_over": sst[2], "pairs_started": sst[3], "debug": list(sst[4:])},
                        "step": "pack + sort + align + D2H results" + (" + RCCL all-gather" if use_dist else "")},
             "pairs_per_s": total_pairs * a.steps / elapsed,
             "kernel_ms": kernel_ms,

@@ -193,6 +193,12 @@ int agatha_amd_kernel_choice(void* stream, const void* d_workspace, uint32_t n_a
  * lane group executes, out[2] = lane groups used.  All 0 when the work queue was used.  Synchronises the stream. */
 int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_alns, int out[3]);
 
+/* Diagnostics: what the packed-int16 kernel's steps were in the last agatha_amd_align() on this workspace: out[0] = wave-steps
+ * on packed maxima of H alone ("value steps"), out[1] = wave-steps with H : column keys ("key steps": a pair's last steps,
+ * pairs that were started over), out[2] = pairs started over on key steps (z-drop came into reach on a value step, or the
+ * pair ended without knowing the cell of its maximum), out[3] = pairs started.  Synchronises the stream. */
+int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[16]);
+
 /* Diagnostics (debug option "timeline" = 1, workspace sized for > 4096 pairs): where and when every wave of the packed-int16
  * kernel ran in the last agatha_amd_align() on this workspace.  8 dwords per wave (wave = 4 * workgroup + wave in
  * workgroup): start and end in ticks of the 100 MHz real-time counter, HW_ID, XCC_ID, steps executed, pairs started, 2

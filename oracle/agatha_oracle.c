@@ -349,6 +349,13 @@ int agatha_model_traceback(const char *qs, int Q, const char *rs, int R, const o
 /* row state handed from block (q,r) to block (q,r+1), eager z-drop checks.  This is the         */
 /* schedule of the HIP kernel; it must agree with agatha_model_slices() bit for bit.             */
 /* ------------------------------------------------------------------------------------------ */
+/* Step statistics for the design of the kernel's fast path (tools/step_stats.py; not a result): when non-NULL,
+ * agatha_model_steps() fills st[0] = steps run, st[1] = step of the last rise of the running maximum (-1: none),
+ * st[2] = steps (with all 8 anti-diagonals inside the pair) on which z-drop could fire judging by the values alone
+ * (max(best, largest H) - smallest anti-diagonal maximum > z), st[3] = the first such step (-1: none),
+ * st[4] = 1 if the pair stopped on z-drop, st[5] = steps that raised the maximum, st[6] = total steps of the pair. */
+__thread int32_t *agatha_steps_stats = 0;
+
 void agatha_model_steps(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr,
                         int wide, oracle_result_t *out)
 {
@@ -393,6 +400,18 @@ void agatha_model_steps(const char *qs, int Q, const char *rs, int R, const orac
                 }
                 block_rows(&cx, q, r, cs, ce, H[r], F[r], P[r]);
             }
+            if (agatha_steps_stats) {
+                int32_t *st = agatha_steps_stats;
+                int hmin = INT_MAX, hmax = INT_MIN;
+                for (int d = 8 * i; d < 8 * i + 8 && d < lim; d++) {
+                    int Hh, c; dmax_get(&cx.dmax[d % ring], wide, &Hh, &c);
+                    if (Hh < hmin) hmin = Hh;
+                    if (Hh > hmax) hmax = Hh;
+                }
+                st[0] = i + 1;
+                if (8 * i + 7 < lim && z >= 0 && imax(zs.best, hmax) - hmin > z) { st[2]++; if (st[3] < 0) st[3] = i; }
+                if (hmax > zs.best) { st[1] = i; st[5]++; }
+            }
             /* anti-diagonals 8i..8i+7 are complete after step i */
             for (int d = 8 * i; d < 8 * i + 8 && d < lim; d++) {
                 int Hh, c; dmax_get(&cx.dmax[d % ring], wide, &Hh, &c);
@@ -413,7 +432,26 @@ void agatha_model_steps(const char *qs, int Q, const char *rs, int R, const orac
         }
     }
     out->score = zs.best; out->query_end = zs.best_q; out->target_end = zs.best_t;
+    if (agatha_steps_stats) { agatha_steps_stats[4] = zs.stopped && !done && i0 < total; agatha_steps_stats[6] = total; }
     free(H); free(started); free(cx.rowH); free(cx.dmax); free(qc); free(rc);
+}
+
+void agatha_steps_stats_batch(const uint8_t *qbatch, const uint8_t *tbatch, const uint32_t *qoff, const uint32_t *toff,
+                              const uint32_t *qlen, const uint32_t *tlen, int n, const oracle_params_t *pr, int threads,
+                              int32_t *stats7)
+{
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int k = 0; k < n; k++) {
+        oracle_result_t res;
+        int32_t *st = stats7 + 7 * (size_t)k;
+        st[0] = 0; st[1] = -1; st[2] = 0; st[3] = -1; st[4] = 0; st[5] = 0; st[6] = 0;
+        agatha_steps_stats = st;
+        agatha_model_steps((const char *)qbatch + qoff[k], (int)qlen[k], (const char *)tbatch + toff[k], (int)tlen[k], pr, 1, &res);
+        agatha_steps_stats = 0;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------ */
