@@ -460,12 +460,12 @@ int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_a
     return 0;
 }
 
-int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[16])
+int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[40])
 {
     if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
     const char* ws = (const char*)d_workspace;
     ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets);
-    hipError_t e = hipMemcpyAsync(out, ws + 20 * sizeof(unsigned int), 16 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    hipError_t e = hipMemcpyAsync(out, ws + 20 * sizeof(unsigned int), 40 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "agatha_amd_step_stats");
     return 0;

@@ -359,7 +359,7 @@ class DeviceBatch:
         """(value wave-steps, key wave-steps, pairs started over, pairs started) of the int16 kernel in the last align()."""
         lib = self.eng.lib
         st = stream if stream is not None else self.eng.stream
-        c = (C.c_uint * 16)()
+        c = (C.c_uint * 40)()
         _chk(lib, lib.agatha_amd_step_stats(st, self.d_ws.ptr, self.n, c))
         return tuple(int(v) for v in c)
 

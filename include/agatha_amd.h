@@ -197,7 +197,7 @@ int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_a
  * on packed maxima of H alone ("value steps"), out[1] = wave-steps with H : column keys ("key steps": a pair's last steps,
  * pairs that were started over), out[2] = pairs started over on key steps (z-drop came into reach on a value step, or the
  * pair ended without knowing the cell of its maximum), out[3] = pairs started.  Synchronises the stream. */
-int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[16]);
+int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[40]);
 
 /* Diagnostics (debug option "timeline" = 1, workspace sized for > 4096 pairs): where and when every wave of the packed-int16
  * kernel ran in the last agatha_amd_align() on this workspace.  8 dwords per wave (wave = 4 * workgroup + wave in

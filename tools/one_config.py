@@ -17,5 +17,5 @@ b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); eng.synchronize()
 sc = agatha_amd.Scores.make(**p)
 for rep in range(3):
     e0, e1 = eng.event(), eng.event(); eng.record(e0); b.align(sc); eng.record(e1); ms = eng.elapsed_ms(e0, e1)
-    print(name, b.kernel_choice(), round(ms, 2), "ms", round(cells / ms / 1e6, 1), "GCUPS", "pair-steps", steps, "cells", cells, flush=True)
+    print(name, b.kernel_choice(), round(ms, 2), "ms", round(cells / ms / 1e6, 1), "GCUPS", "pair-steps", steps, "cells", cells, "steps", b.step_stats(), "kinds", b.pair_kinds(), flush=True)
 b.free()
