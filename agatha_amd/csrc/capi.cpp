@@ -40,8 +40,9 @@ DebugOption g_opts[] = {
     {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts)
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
     {"fast_margin", "AGATHA_AMD_FAST_MARGIN", {16}},   // int16 kernel: value steps except in a pair's last n steps; 0: key steps only
+    {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {4096}},   // int16 kernel: pairs of at least this many steps take checkpoints (0: none do)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FAST_MARGIN, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FAST_MARGIN, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -82,6 +83,24 @@ size_t mig_workspace_bytes(uint32_t n)
            round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords) + agatha::kMigBufBytes;
 }
 
+// Checkpoint area of the packed-int16 kernel (two slots of a suspended pair's size per lane group that can be in flight: the
+// largest of its shapes' needs, never more lane groups than pairs)
+struct CkShape { int G, P; };
+const CkShape kCkShapes[] = {{16, 1}, {16, 2}, {16, 3}, {32, 2}, {32, 3}, {64, 1}, {64, 2}, {128, 1}};
+size_t ck_groups(int G, uint32_t n)
+{
+    const size_t cus = (size_t)num_cus();
+    const size_t groups = G == 128 ? cus * 4 : cus * 8 * (size_t)(64 / G);
+    return std::min<size_t>(groups, (size_t)n + 16);       // (a grid of whole workgroups: up to 16 lane groups each)
+}
+size_t ck_workspace_bytes(uint32_t n)
+{
+    size_t need = 0;
+    for (const CkShape& s : kCkShapes)
+        need = std::max(need, ck_groups(s.G, n) * 2 * (size_t)agatha::align16_mig_fields(s.P) * (size_t)s.G * sizeof(uint32_t));
+    return round_up(need);
+}
+
 }  // namespace
 
 extern "C" {
@@ -114,6 +133,13 @@ int agatha_amd_max_band(void) { return (agatha::max_window_blocks() - 1) * 8; }
 size_t agatha_amd_workspace_bytes(uint32_t max_n_alns)
 {
     return base_workspace_bytes(max_n_alns) + (max_n_alns > kMigMinPairs ? mig_workspace_bytes(max_n_alns) : 0);
+}
+
+size_t agatha_amd_workspace_bytes_long(uint32_t max_n_alns, uint32_t max_query_len, uint32_t max_target_len)
+{
+    const bool is_long = !max_query_len || !max_target_len ||
+                         ((size_t)max_query_len + 7) / 8 + ((size_t)max_target_len + 7) / 8 >= (size_t)std::max(opt(OPT_CK_MIN_STEPS), 1);
+    return agatha_amd_workspace_bytes(max_n_alns) + ((is_long && opt(OPT_CK_MIN_STEPS) > 0) ? ck_workspace_bytes(max_n_alns) : 0);
 }
 
 int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, uint32_t* d_packed)
@@ -232,6 +258,9 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     int* mig_state = (int*)ws;                               ws += round_up(sizeof(int) * (agatha::kMigMaxSlots + 1));
     uint32_t* timeline = (uint32_t*)ws;                      ws += round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords);
     uint32_t* mig_buf = (uint32_t*)ws;
+    // the checkpoint area lies behind everything else (behind the schedule's areas when the workspace holds them)
+    const size_t ck_off = base_workspace_bytes(n_alns) + ((n_alns > kMigMinPairs && workspace_bytes >= base_workspace_bytes(n_alns) + mig_workspace_bytes(n_alns)) ? mig_workspace_bytes(n_alns) : 0);
+    const bool have_ck = workspace_bytes >= ck_off + ck_workspace_bytes(n_alns) && opt(OPT_CK_MIN_STEPS) > 0;
 
     // inside the 256-byte queue block: [0..3] queue heads, [8] step totals, [10] kernel choice, [12] pair-kind counters,
     // [16..18] the schedule, [20..23] step statistics of the int16 kernel
@@ -290,6 +319,9 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.mig_timeout_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TIMEOUT_US), 0);
     L.mig_test_delay_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TEST_DELAY_US), 0);
     L.fast_margin = std::max(opt(OPT_FAST_MARGIN), 0);
+    L.ck_buf = have_ck ? (uint32_t*)((char*)d_workspace + ck_off) : nullptr;
+    L.ck_slots = 1 << 30;           // (the area is sized for every lane group any shape's grid can have for this many pairs)
+    L.ck_min_steps = opt(OPT_CK_MIN_STEPS);
     L.max_blocks_override = opt(OPT_MAX_BLOCKS);
     L.no_deal = opt(OPT_NO_DEAL) ? 1 : 0;
     // Candidates for the plain pairs: the packed-int16 kernel when the scores and the band allow it, the int32 kernel

@@ -53,6 +53,9 @@ struct AlignLaunch {
     int prio_duty;                 // of every 16 slices, the wave in slot 0 of its SIMD is the favoured one in this many
     unsigned int mig_test_delay_ticks;   // tests: odd lane groups sleep this long before they start (forces the take-over)
     unsigned int* step_stats;      // device: [0] value wave-steps, [1] key wave-steps, [2] pairs started over, [3] pairs started (int16 kernel)
+    uint32_t* ck_buf;              // device: checkpoints of the int16 kernel's long pairs, two slots of a suspended pair's size per lane group (nullptr: none)
+    int ck_slots;                  // lane groups the area has room for
+    int ck_min_steps;              // pairs of fewer steps take no checkpoints
     int fast_margin;               // packed-int16 kernel: > 0 = value steps (align16_body.inc) except in a pair's last fast_margin steps; 0 = key steps only
     // ---- traceback pass (align_tb.hip): the compare kernel also records a 4-bit code per computed cell ----
     uint32_t* tb_codes;            // device: the code area; pair k's words start at tb_off[k]: 8 words (one per block row, a

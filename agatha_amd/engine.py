@@ -66,6 +66,8 @@ def load_library():
     lib.agatha_amd_max_band.restype = C.c_int
     lib.agatha_amd_workspace_bytes.restype = C.c_size_t
     lib.agatha_amd_workspace_bytes.argtypes = [C.c_uint32]
+    lib.agatha_amd_workspace_bytes_long.restype = C.c_size_t
+    lib.agatha_amd_workspace_bytes_long.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.agatha_amd_pack.argtypes = [vp, vp, C.c_uint32, u32p]
     lib.agatha_amd_pack_host.argtypes = [vp, C.c_size_t, u32p]
     lib.agatha_amd_seq_ops.argtypes = [vp, vp, u32p, u32p, u32p, vp, C.c_uint32]
@@ -113,7 +115,7 @@ def load_library():
 
 EXPORTS = [
     "agatha_amd_strerror", "agatha_amd_last_error", "agatha_amd_version", "agatha_amd_device_count",
-    "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_pack", "agatha_amd_pack_host",
+    "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_workspace_bytes_long", "agatha_amd_pack", "agatha_amd_pack_host",
     "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_starts_scratch_bytes", "agatha_amd_align_starts", "agatha_amd_traceback_pair_bytes",
     "agatha_amd_traceback_scratch_bytes",
     "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_step_stats", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
@@ -205,7 +207,7 @@ class DeviceBatch:
         self.d_pk_t = _DevBuf(lib, tb.size // 2 + 16)
         self.d_meta = [_DevBuf(lib, 4 * self.n) for _ in range(4)]
         self.d_res = [_DevBuf(lib, 4 * self.n) for _ in range(3)]
-        self.ws_bytes = lib.agatha_amd_workspace_bytes(self.n)
+        self.ws_bytes = lib.agatha_amd_workspace_bytes_long(self.n, max(self.max_qlen, 1), max(self.max_tlen, 1))
         self.d_ws = _DevBuf(lib, self.ws_bytes)
         # results land in pinned host memory (as the reference's cudaHostAlloc'd host_res, ctors.cpp): the D2H copy is
         # then really asynchronous and the host can enqueue the next batch while this one runs

@@ -48,7 +48,7 @@ template <typename T> T* pin_realloc(T* src, int new_n, int old_n)
 
 uint32_t pad8(uint32_t v) { return (v + 7u) & ~7u; }
 
-void alloc_device_meta(gasal_gpu_storage_t* s, uint32_t n)
+void alloc_device_meta(gasal_gpu_storage_t* s, uint32_t n, uint32_t max_query_len = 0, uint32_t max_target_len = 0)
 {
     s->query_batch_lens = dev_alloc<uint32_t>(n);
     s->target_batch_lens = dev_alloc<uint32_t>(n);
@@ -56,7 +56,7 @@ void alloc_device_meta(gasal_gpu_storage_t* s, uint32_t n)
     s->target_batch_offsets = dev_alloc<uint32_t>(n);
     s->query_op = dev_alloc<uint8_t>(n);
     s->target_op = dev_alloc<uint8_t>(n);
-    s->workspace_bytes = agatha_amd_workspace_bytes(n);
+    s->workspace_bytes = agatha_amd_workspace_bytes_long(n, max_query_len, max_target_len);
     s->workspace = dev_alloc<uint8_t>(s->workspace_bytes);
 }
 void free_device_meta(gasal_gpu_storage_t* s)
@@ -289,7 +289,7 @@ void gasal_init_streams(gasal_gpu_storage_v* vec, int max_query_len, int max_tar
         s->host_target_batch_lens = pin_alloc<uint32_t>(n);
         s->host_query_batch_offsets = pin_alloc<uint32_t>(n);
         s->host_target_batch_offsets = pin_alloc<uint32_t>(n);
-        alloc_device_meta(s, n);
+        alloc_device_meta(s, n, (uint32_t)std::max(max_query_len, 1), (uint32_t)std::max(max_target_len, 1));
         s->host_res = gasal_res_new_host(n, params);
         s->device_cpy = gasal_res_new_device_cpy(n, params);
         s->device_res = gasal_res_new_device(s->device_cpy);

@@ -421,3 +421,107 @@ def test_one_pair_on_two_cooperating_waves(eng):
         finally:
             agatha_amd.set_debug_option("force_int16", 1)
         assert _same(got, exp)
+
+
+# ---- value steps (packed maxima of H alone), pairs that are started over, checkpoints ----
+def _run_stats(eng, qs, ts, p, **opts):
+    """align under debug options; returns (got, exp, step_stats, pair kinds)"""
+    qb, qo, ql = WL.make_batch(qs)
+    tb, to, tl = WL.make_batch(ts)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=8)
+    with agatha_amd.debug_options(**opts):
+        b = eng.batch(qb, tb, qo, to, ql, tl)
+        try:
+            b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
+            got = [b.res_host[j].copy() for j in range(3)]
+            st, kinds = b.step_stats(), b.pair_kinds()
+        finally:
+            b.free()
+    return got, exp, st, kinds
+
+
+def _broken_batch(seed, n, lo, hi, broken=0.3, noisy=0.2):
+    rng = np.random.default_rng(seed)
+    qs, ts = [], []
+    for _ in range(n):
+        ref = WL.random_seq(rng, int(rng.integers(lo, hi)))
+        u = rng.random()
+        if u < broken:          # unrelated behind a breakpoint: z-drop comes into reach long after the last rise of the maximum
+            bp = int(rng.integers(ref.size // 4, ref.size))
+            rd = np.concatenate([WL.mutate(rng, ref[:bp], 0.03, 0.03, 0.04), WL.random_seq(rng, ref.size - bp + 1)])
+        elif u < broken + noisy:   # so noisy that the maximum keeps sinking and recovering
+            e = rng.uniform(0.25, 0.4) / 3
+            rd = WL.mutate(rng, ref, e, e, e)
+        else:
+            rd = WL.mutate(rng, ref, 0.03, 0.03, 0.04)
+        if rd.size == 0:
+            rd = WL.random_seq(rng, 1)
+        qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    return qs, ts
+
+
+@pytest.mark.parametrize("margin", [1, 4, 16, 64])
+def test_value_steps_and_pairs_started_over(eng, margin):
+    """Steps that only track the VALUES of the anti-diagonal maxima (one instruction per cell pair instead of three) decide
+    nothing but the running maximum; a pair on which z-drop comes into reach, or that ends without a rise of the maximum on
+    a key step, is started over on key steps.  Results bit-exact for every width of the window of key steps at a pair's end."""
+    qs, ts = _broken_batch(61 + margin, 300, 400, 5000)
+    for p in (BASE, dict(BASE, z=100, w=100), dict(m=1, x=4, q=6, r=2, s=1, z=200, w=500)):
+        got, exp, st, kinds = _run_stats(eng, qs, ts, p, fast_margin=margin, ck_min_steps=0)
+        assert _same(got, exp)
+        assert st[0] > 0 and st[1] > 0    # value steps and key steps
+        assert st[2] > 0                  # pairs were started over (from their first step: no checkpoints here)
+        assert kinds[2] == 0              # and none of that went to the int32 kernel
+    got, exp, st, _ = _run_stats(eng, qs, ts, BASE, fast_margin=0)
+    assert _same(got, exp) and st[0] == 0 and st[2] == 0          # key steps only: the kernel of round 2
+
+
+@pytest.mark.parametrize("shape", [0, 1])
+def test_checkpoints_and_going_back_to_them(eng, shape):
+    """Long pairs save their state every eighth of their steps; a pair that must be started over goes back to the last
+    checkpoint before the final rise of its maximum and runs key steps from there.  Forced on short pairs here
+    (ck_min_steps = 32: a checkpoint every 256 steps), on the throughput shape and on the latency shape."""
+    qs, ts = _broken_batch(71, 240, 6000, 12000, broken=0.5, noisy=0.1)
+    p = dict(BASE, z=120)
+    agatha_amd.set_debug_option("force_choice", shape)
+    try:
+        got, exp, st, kinds = _run_stats(eng, qs, ts, p, ck_min_steps=32)
+        assert _same(got, exp)
+        assert st[15] > 20                # pairs went back to a checkpoint
+        assert kinds[2] == 0
+        got, exp, st, _ = _run_stats(eng, qs, ts, p, ck_min_steps=0)
+        assert _same(got, exp) and st[15] == 0 and st[2] > 20
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
+
+
+def test_two_wave_shape_moves_the_base_under_a_barrier(eng):
+    """One pair on two waves, more workgroups than CUs (two and more per CU, so the waves of a pair drift apart in time) and
+    scores that move the base of the representation several times per pair: the E hand-off values of the lanes at the wave
+    boundary are read by the other wave at the start of its next step, so moving them to the new base needs a barrier
+    behind it (found in round 3 as values off by 2048 once steps became shorter)."""
+    rng = np.random.default_rng(83)
+    qs, ts = [], []
+    for _ in range(700):
+        ref = WL.random_seq(rng, int(rng.integers(5000, 7000)))
+        qs.append(ref.tobytes()); ts.append(WL.mutate(rng, ref, 0.02, 0.02, 0.02).tobytes())
+    p = dict(BASE, w=1500)
+    agatha_amd.set_debug_option("force_int16", 0)
+    agatha_amd.set_debug_option("force_choice", 1)            # the latency shape of this window: <128, 1>
+    try:
+        qb, qo, ql = WL.make_batch(qs)
+        tb, to, tl = WL.make_batch(ts)
+        exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_STEPS, threads=8)
+        b = eng.batch(qb, tb, qo, to, ql, tl)
+        try:
+            for _ in range(3):
+                b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
+                got = [b.res_host[j].copy() for j in range(3)]
+                assert b.kernel_choice() == ("int16", 128, 2)
+                assert _same(got, exp)
+                assert b.step_stats()[2] == 0 and b.step_stats()[15] == 0       # nothing had to be started over
+        finally:
+            b.free()
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
+        agatha_amd.set_debug_option("force_int16", 1)

@@ -47,7 +47,9 @@ while time.time() < t_end:
         qs.append(ref.tobytes()); ts.append(rd.tobytes())
     qb, qo, ql = WL.make_batch(qs); tb, to, tl = WL.make_batch(ts)
     exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=16)
-    for mode, opts in (("choice", {}), ("int16", {"force_int16": 1}), ("int32", {"no_int16": 1})):
+    # (value steps of the int16 kernel: the window of key steps at a pair's end and the checkpoints vary as well)
+    vs = dict(fast_margin=int(rng.choice([0, 1, 3, 8, 16, 64])), ck_min_steps=int(rng.choice([0, 16, 256, 4096])))
+    for mode, opts in (("choice", dict(vs)), ("int16", dict(vs, force_int16=1)), ("int32", {"no_int16": 1})):
         with agatha_amd.debug_options(**opts):
             got = eng.align_host_batch(qb, tb, qo, to, ql, tl, agatha_amd.Scores.make(**p), use_len_hint=bool(rng.integers(0, 2)))
         diff = [i for i in range(len(ql)) if any(int(exp[j][i]) != int(got[j][i]) for j in range(3))]

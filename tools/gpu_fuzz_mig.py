@@ -47,7 +47,8 @@ while time.time() < t_end:
     force_takeover = rng.random() < 0.25
     for mode, opts in (("static", dict(mig_timeout_us=500, mig_test_delay_us=int(rng.integers(2000, 30000))) if force_takeover else {}),
                        ("queue", dict(no_migrate=1))):
-        with agatha_amd.debug_options(force_int16=1, **opts):
+        vs = dict(fast_margin=int(rng.choice([0, 2, 16, 40])), ck_min_steps=int(rng.choice([0, 16, 4096])))       # value steps, checkpoints
+        with agatha_amd.debug_options(force_int16=1, **vs, **opts):
             b = eng.batch(qb, tb, qo, to, ql, tl)
             try:
                 b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
