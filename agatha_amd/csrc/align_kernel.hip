@@ -380,7 +380,7 @@ schedule_kernel(AlignLaunch L, int GS, int G)
     __shared__ uint32_t pmaxs[1024];
     __shared__ uint32_t nzs[1024];
     const int n = L.n, m = L.mig_slots, t = threadIdx.x;
-    if (!L.mig_enabled || m <= 0 || n <= m || ((long long)n > 16ll * m && L.mig_enabled != 2)) { if (t == 0) L.sched[0] = 0; return; }
+    if (!L.mig_enabled || m <= 0 || n <= m || ((long long)n > 16ll * m && L.mig_enabled != 2)) { if (t == 0) { L.sched[0] = 0; L.sched[1] = 0; L.sched[2] = 0; } return; }
     const int W = (L.p.band_width + 7) >> 3, sw = L.p.slice_width;
     const int chunk = (n + 1023) / 1024;
     const int j0 = t * chunk, j1 = min(n, j0 + chunk);
@@ -412,7 +412,7 @@ schedule_kernel(AlignLaunch L, int GS, int G)
         // beyond that the queue balances by itself (70 000 pairs: 223.7 against 227.2 ms) and also follows pairs that z-drop early.
         const long long pavg = npairs ? P / (long long)npairs : 0;
         const bool use = pm > 0 && P < (1ll << 30) && (L.mig_enabled == 2 || 10ll * n <= 22ll * m || pavg >= 12ll * (W + 1));
-        L.sched[0] = use ? 1 : 0; L.sched[1] = (int)T; L.sched[2] = (int)((P + T - 1) / T);
+        L.sched[0] = use ? 1 : 0; L.sched[1] = use ? (int)T : 0; L.sched[2] = use ? (int)((P + T - 1) / T) : 0;
     }
     __syncthreads();
     uint32_t acc = part[t];

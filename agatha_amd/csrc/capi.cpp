@@ -451,7 +451,11 @@ int agatha_amd_align_starts(void* stream, const uint32_t* d_packed_query, const 
     HIPCHK(agatha::launch_reverse_prefix(d_packed_query, rq, d_query_offsets, d_query_batch_end, rql, n_alns, st));
     HIPCHK(agatha::launch_reverse_prefix(d_packed_target, rt, d_target_offsets, d_target_batch_end, rtl, n_alns, st));
     agatha_amd_scores back = *sc;
-    back.z_threshold = -1;                      // the alignment is known to exist: no z-drop on the way back
+    // The alignment is known to exist: no z-drop on the way back.  Not z = -1, which would arm the range check for scores
+    // that sink without bound (it refuses reads of ~127 kb at band 1500): from the end cell back along the alignment every
+    // partial score is >= 0 (the end cell holds the maximum over all prefixes), and cells off the path lie at most a band
+    // width below it, so a threshold no drop can reach means the same and checks nothing.
+    back.z_threshold = 1 << 24;
     const int rc = agatha_amd_align(stream, rq, rt, rql, rtl, d_query_offsets, d_target_offsets, n_alns, max_query_len, max_target_len,
                                     &back, bs, bq, bt, d_workspace, workspace_bytes);
     if (rc != 0) return rc;
@@ -506,6 +510,8 @@ int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns
 int agatha_amd_timeline(void* stream, const void* d_workspace, uint32_t n_alns, uint32_t* out, uint32_t max_waves)
 {
     if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
+    // the timeline area is part of the schedule's areas: only workspaces sized for more than kMigMinPairs pairs have it
+    if (n_alns <= kMigMinPairs) { snprintf(g_err, sizeof(g_err), "agatha_amd_timeline: workspaces for <= %u pairs hold no timeline area", kMigMinPairs); return AGATHA_AMD_EWORKSPACE; }
     const char* ws = (const char*)d_workspace;
     ws += base_workspace_bytes(n_alns) + round_up(sizeof(uint32_t) * ((size_t)n_alns + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1));
     const uint32_t nw = std::min<uint32_t>(max_waves, agatha::kTimelineWaves);

@@ -69,7 +69,9 @@ void Parameters::help()
     std::cerr << "         -n INT    number of CPU threads [" << n_threads << "]" << std::endl;
     std::cerr << "         -c        apply the reverse/complement codes of the FASTA header characters (> < / +)" << std::endl;
     std::cerr << "         -k        pack the sequences on the host and ship pre-packed batches (isPacked): half the H2D bytes" << std::endl;
-    std::cerr << "         -S        also compute and print the start positions (query_batch_start / target_batch_start)" << std::endl;
+    std::cerr << "         -S        also compute and print the start positions (query_batch_start / target_batch_start):" << std::endl;
+    std::cerr << "                   where the best alignment ENDING in the end cell begins (local-style trimming; not the first cell of the -T path," << std::endl;
+    std::cerr << "                   which is the extension alignment and always starts at the origin)" << std::endl;
     std::cerr << "         -T        also compute and print the alignment paths (cigar / n_cigar_ops)" << std::endl;
     std::cerr << "         -g INT    spread the CPU threads over this many GPUs [" << n_gpus << "]" << std::endl;
     std::cerr << "         --help, -h : displays this message." << std::endl;

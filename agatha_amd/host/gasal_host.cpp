@@ -377,8 +377,12 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
     if (actual_target_batch_bytes <= 0) { fprintf(stderr, "[GASAL ERROR:] actual_target_batch_bytes <= 0\n"); exit(EXIT_FAILURE); }
     if (actual_query_batch_bytes % 8) { fprintf(stderr, "[GASAL ERROR:] actual_query_batch_bytes=%d is not a multiple of 8\n", actual_query_batch_bytes); exit(EXIT_FAILURE); }
     if (actual_target_batch_bytes % 8) { fprintf(stderr, "[GASAL ERROR:] actual_target_batch_bytes=%d is not a multiple of 8\n", actual_target_batch_bytes); exit(EXIT_FAILURE); }
-    if (actual_query_batch_bytes > s->host_max_query_batch_bytes) { fprintf(stderr, "[GASAL ERROR:] actual_query_batch_bytes(%d) > host_max_query_batch_bytes(%d)\n", actual_query_batch_bytes, s->host_max_query_batch_bytes); exit(EXIT_FAILURE); }
-    if (actual_target_batch_bytes > s->host_max_target_batch_bytes) { fprintf(stderr, "[GASAL ERROR:] actual_target_batch_bytes(%d) > host_max_target_batch_bytes(%d)\n", actual_target_batch_bytes, s->host_max_target_batch_bytes); exit(EXIT_FAILURE); }
+    // (storages created with isPacked keep their pages -- and host_max_*_batch_bytes -- in PACKED bytes, gasal_host_batch_fill_packed:
+    //  a batch of `actual` unpacked-equivalent bytes occupies actual / 2 of them)
+    const uint32_t host_q = params->isPacked ? actual_query_batch_bytes / 2 : actual_query_batch_bytes;
+    const uint32_t host_t = params->isPacked ? actual_target_batch_bytes / 2 : actual_target_batch_bytes;
+    if (host_q > s->host_max_query_batch_bytes) { fprintf(stderr, "[GASAL ERROR:] actual_query_batch_bytes(%d) > host_max_query_batch_bytes(%d)\n", actual_query_batch_bytes, s->host_max_query_batch_bytes); exit(EXIT_FAILURE); }
+    if (host_t > s->host_max_target_batch_bytes) { fprintf(stderr, "[GASAL ERROR:] actual_target_batch_bytes(%d) > host_max_target_batch_bytes(%d)\n", actual_target_batch_bytes, s->host_max_target_batch_bytes); exit(EXIT_FAILURE); }
     if (actual_n_alns > s->host_max_n_alns) { fprintf(stderr, "[GASAL ERROR:] actual_n_alns(%d) > host_max_n_alns(%d)\n", actual_n_alns, s->host_max_n_alns); exit(EXIT_FAILURE); }
 
     // grow device buffers to a multiple of their current size (gasal_align.cu:71-133)
@@ -491,7 +495,7 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
         exit(EXIT_FAILURE);
     }
     CHK(rc);
-    if (params->print_out) { CHK(agatha_amd_event_record(s->ev_end, s->str)); s->timing_pending = 1; s->timing_params = params; }
+    if (params->print_out) { CHK(agatha_amd_event_record(s->ev_end, s->str)); s->timing_pending = 1; s->timing_params = params; s->timing_n_alns = actual_n_alns; }
 
     if (params->start_pos) {
         // start positions (extension; the reference copies them back only if they are not NULL, gasal_align.cu:256-260, and they
@@ -545,6 +549,20 @@ int gasal_is_aln_async_done(gasal_gpu_storage_t* s)
         CHK(agatha_amd_event_elapsed_ms(s->ev_begin, s->ev_end, &ms));
         Parameters* p = (Parameters*)s->timing_params;
         if (p) { std::lock_guard<std::mutex> lock(g_raw_mutex); p->raw_file << ms << std::endl; }
+        // (measurement aid, not part of the reference's protocol: with AGATHA_AMD_RAW_STATS=<file> every batch also leaves a
+        //  line "n_alns kernel_ms value_steps key_steps started_over went_back_to_checkpoint taken_over" there --
+        //  agatha_amd_step_stats; taken_over counts the pairs a lane group took from a neighbour that did not show up in time)
+        static const char* stats_path = getenv("AGATHA_AMD_RAW_STATS");
+        if (stats_path && *stats_path) {
+            unsigned int st[40] = {0};
+            if (agatha_amd_step_stats(s->str, s->workspace, s->timing_n_alns, st) == 0) {
+                std::lock_guard<std::mutex> lock(g_raw_mutex);
+                if (FILE* f = fopen(stats_path, "a")) {
+                    fprintf(f, "%u %.4f %u %u %u %u %u\n", s->timing_n_alns, ms, st[0], st[1], st[2], st[15], st[14]);
+                    fclose(f);
+                }
+            }
+        }
         s->timing_pending = 0;
         s->timing_params = nullptr;
     }

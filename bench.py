@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank aligns its own batch; strong: ONE batch, LPT-sharded over the ranks, results gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gasal-api", action="store_true", help="skip the timing of the CLI / GASAL API by the reference's raw.log protocol")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     if a.pairs <= 0:
@@ -304,6 +305,25 @@ def main():
                               "note": "lane-ops the recurrence itself needs per cell x cells/s over the measured VALU issue "
                                       "rate of the chip; the int16 kernel does two cells per packed lane-op"},
         }
+        if world == 1 and not a.no_gasal_api and a.config in ("C0", "C1"):
+            # The same batch through the product's real entry point, by the reference's own protocol (AGAThA.sh:44,52: `manual -p`,
+            # sum of raw.log): FASTA files -> CLI -> gasal_aln_async on two streams per host thread -> kernel ms per batch written
+            # by the library.  After the timed loop; a child process (its own context on the same GPU).
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import gasal_api_timing
+            try:
+                qs_host = [qb[int(o):int(o) + int(l)].tobytes() for o, l in zip(qo, ql)]
+                ts_host = [tb[int(o):int(o) + int(l)].tobytes() for o, l in zip(to, tl)]
+                runs = gasal_api_timing.time_config(qs_host, ts_host, cfg["scoring"], W_BAND, Z, combos=((a.pairs, 1), (8192, 1)))
+                del qs_host, ts_host
+                for r in runs:
+                    r.pop("per_batch"); r.pop("score_log")
+                out["gasal_api"] = {"protocol": "agatha_amd/manual -p (reference AGAThA.sh:44,52, gasal_align.cu:219-236): kernel ms per batch as written to raw.log by libgasal_amd.so; two streams per host thread",
+                                    "runs": runs,
+                                    "kernel_ms_per_batch_of_all_pairs": runs[0]["kernel_ms_sum"],
+                                    "vs_kernel_ms": runs[0]["kernel_ms_sum"] / kernel_ms if kernel_ms else None}
+            except Exception as e:          # (a missing CLI binary must not cost the bench line)
+                out["gasal_api"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             gpu_res = tuple(np.array(b.res_host[j][:b.n]) for j in range(3))      # downloaded by the last step
             out["cpu_baseline"] = cpu_baseline(qb, tb, qo, to, ql, tl, dict(s=3, z=Z, w=W_BAND, **cfg["scoring"]), W_BAND,

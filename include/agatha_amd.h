@@ -113,7 +113,12 @@ int agatha_amd_align(void* stream,
  * (0-based inclusive, like the ends).  Call after agatha_amd_align() on the same stream, with its end arrays; the packed
  * batches must still be resident.  query_batch_bytes / target_batch_bytes: sizes of the UNPACKED layout (what
  * gasal_aln_async takes).  d_scratch: agatha_amd_starts_scratch_bytes() of device memory; d_workspace as for
- * agatha_amd_align (the same one may be used).  Costs about one more agatha_amd_align of the batch. */
+ * agatha_amd_align (the same one may be used).  Costs about one more agatha_amd_align of the batch.
+ * NOTE: these are the starts of a LOCAL-style trimming of the extension -- where the best-scoring alignment ending in the end
+ * cell begins; it may begin after the origin and, banded around the end cell's diagonal, may leave the forward band.  They are
+ * NOT the first cell of the path agatha_amd_align_traceback() reports: that path is the extension alignment itself and
+ * always starts at the origin (0, 0).  A caller that prints both (`manual -S -T`) shows two different alignments of the
+ * same end cell. */
 size_t agatha_amd_starts_scratch_bytes(uint32_t query_batch_bytes, uint32_t target_batch_bytes, uint32_t max_n_alns);
 int agatha_amd_align_starts(void* stream, const uint32_t* d_packed_query, const uint32_t* d_packed_target,
                             const uint32_t* d_query_offsets, const uint32_t* d_target_offsets, uint32_t n_alns,

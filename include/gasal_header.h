@@ -120,6 +120,7 @@ typedef struct {
     void* ev_begin;                     /* hipEvent_t pair for the -p timing mode */
     void* ev_end;
     int timing_pending;
+    uint32_t timing_n_alns;                      /* pairs of the batch whose kernel time is pending (-p) */
     void* starts_scratch;               /* device scratch of agatha_amd_align_starts (only with params->start_pos) */
     size_t starts_scratch_bytes;
     void* tb_scratch;                   /* device scratch of agatha_amd_align_traceback (only with params->traceback) */

@@ -43,6 +43,7 @@ typedef struct {
     int32_t xh[MAXS + 1][8], xe[MAXS + 1][8];
     int xr[MAXS + 1];
     int32_t A[15];
+    int32_t AV[2][15];      /* value steps of the int16 kernel: maxima of H alone, per half (even / odd slots) of the lane */
 } lane_t;
 
 static void init_col(lane_t *ln, int s, int r, int R, int prl, int w, int gapoe, int ge, const uint32_t *pt)
@@ -292,9 +293,21 @@ static void init_col16(lane_t *ln, int s, int r, int R, int prl, int w, int gapo
     ln->rcur[s] = r;
 }
 
+/* Value steps (align16_body.inc, FAST): with agatha_lanes16_margin > 0 every step except a pair's last `margin` ones only
+ * tracks the VALUES of the anti-diagonal maxima -- per lane and half, as the kernel's packed accumulators do -- and may decide
+ * nothing but the running maximum: it needs the "calm" test (every anti-diagonal maximum, bounded from below by the largest
+ * over lanes and halves of a half's smallest accumulator, within z of the running maximum, well inside its zone, inside the
+ * pair).  A step that is not calm, a key step that needs cells it does not know (the maximum rose on a value step, or the
+ * step's carried accumulators were values: "stale"), or an end without the cell of the maximum returns 2: the caller runs
+ * the pair again on key steps only -- what the kernel does by starting the pair over.  The model keeps exact keys all along;
+ * what it checks is the DECISION logic: whenever it returns 0 with a margin, the result must be the oracle's. */
+__thread int agatha_lanes16_margin = 0;
+
 int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_params_t *pr,
                          int G, int S, int32_t *out3, int32_t *stats)
 {
+    const int margin = agatha_lanes16_margin;
+    int pos_known = 1, prev_fast = 0, again = 0;
     const int a = pr->match, b = pr->mismatch, gapoe = pr->gap_open + pr->gap_extend, ge = pr->gap_extend;
     const int gapo = pr->gap_open;
     const int sw = pr->slice_width, z = pr->z_threshold, w = pr->band_width;
@@ -316,7 +329,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
     for (int k = 0; k < G; k++) {
         for (int s = 0; s < S; s++) init_col16(&L[k], s, k * S + s, R, prl, w, gapoe, ge, base, pt);
         for (int s = 0; s <= S; s++) L[k].xr[s] = -2;
-        for (int x = 0; x < 15; x++) L[k].A[x] = INT_MIN;
+        for (int x = 0; x < 15; x++) { L[k].A[x] = INT_MIN; L[k].AV[0][x] = INT_MIN; L[k].AV[1][x] = INT_MIN; }
     }
     int best = 0, best_t = 0, best_q = 0, stopped = 0, bail = 0;
     int i = 0, y = 0, final = 0, cb_prev = 0;
@@ -388,6 +401,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                         if (il < nrows) {
                             const int32_t key = (int32_t)((uint32_t)hn << K) + crel0 + jl;
                             ln->A[il + jl] = imax(ln->A[il + jl], key);
+                            ln->AV[s & 1][il + jl] = imax(ln->AV[s & 1][il + jl], hn);
                         }
                     }
                     oh[il] = h[7]; oe[il] = e;
@@ -410,12 +424,40 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 memcpy(L[k].xh[0], th[src], sizeof(th[src])); memcpy(L[k].xe[0], te[src], sizeof(te[src])); L[k].xr[0] = tr[src];
             }
         }
+        /* ---- value steps: the calm test on values alone, the mode of this step ---- */
+        const int fast = margin > 0 && i < total - margin;
+        int calm = 0, stale = 0;
+        if (margin > 0) {
+            int32_t lo8 = INT_MIN, mk = INT_MIN;
+            for (int k = 0; k < G; k++)
+                for (int hf = 0; hf < 2; hf++) {
+                    int32_t lo = INT_MAX, hi = INT_MIN;
+                    for (int x = 0; x < 8; x++) {
+                        const int32_t a = L[k].AV[hf][x];
+                        const int32_t v = a == INT_MIN ? INT_MIN : a + (7 - x) * ge;      /* the frame of the step's last anti-diagonal */
+                        if (v < lo) lo = v;
+                        if (v > hi) hi = v;
+                    }
+                    if (lo > lo8) lo8 = lo;
+                    if (hi > mk) mk = hi;
+                }
+            const int64_t base_i = (int64_t)base - (int64_t)ge * (8 * i + 7);
+            calm = !final && (8 * i + 7 < lim) && lo8 != INT_MIN && lo8 >= L16_LO + spread + L16_DELTA + 7 * ge &&
+                   lo8 + base_i >= NEG_INF2 + spread && (z < 0 || imax(best, (int)(mk + base_i)) - (int)(lo8 + base_i) <= z);
+            stale = !fast && prev_fast;
+            if (fast) {
+                if (!calm) { again = 1; break; }
+                if ((int)(mk + base_i) > best) { best = (int)(mk + base_i); pos_known = 0; }
+            } else if (!calm && (stale || !pos_known)) { again = 1; break; }
+            prev_fast = fast;
+        }
         int hi_rep = INT_MIN;
         for (int x = 0; x < 8 && !stopped; x++) {
             int32_t v = INT_MIN;
             for (int k = 0; k < G; k++) v = imax(v, L[k].A[x]);
             const int d = 8 * i + x;
             if (v != INT_MIN && (v >> K) >= L16_LO) hi_rep = imax(hi_rep, v >> K);
+            if (fast) continue;                 /* a value step looks at no anti-diagonal by itself */
             if (!final && d >= lim) continue;
             int H, c;
             if (v == INT_MIN || (v >> K) < L16_GLO) { H = -32768; c = 0; }      /* empty, or only out-of-band cells */
@@ -423,7 +465,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 H = (v >> K) + base - ge * d; c = (v & KMASK) + cb;
                 if ((v >> K) < L16_LO + spread + L16_DELTA || H < NEG_INF2 + spread) { bail = 1; break; }
             }
-            if (H > best) { best = H; best_t = c; best_q = d - c; }
+            if (H > best) { best = H; best_t = c; best_q = d - c; pos_known = !stale; }
             else if (c >= best_t && (d - c) >= best_q) {
                 int tlen = c - best_t, qlen = (d - c) - best_q;
                 int l = tlen > qlen ? tlen - qlen : qlen - tlen;
@@ -432,8 +474,8 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
         }
         if (bail || stopped || final) break;
         for (int k = 0; k < G; k++) {
-            for (int x = 0; x < 7; x++) L[k].A[x] = L[k].A[8 + x];
-            for (int x = 7; x < 15; x++) L[k].A[x] = INT_MIN;
+            for (int x = 0; x < 7; x++) { L[k].A[x] = L[k].A[8 + x]; L[k].AV[0][x] = L[k].AV[0][8 + x]; L[k].AV[1][x] = L[k].AV[1][8 + x]; }
+            for (int x = 7; x < 15; x++) { L[k].A[x] = INT_MIN; L[k].AV[0][x] = INT_MIN; L[k].AV[1][x] = INT_MIN; }
         }
         cb_prev = cb;
         /* rebase: keep the representation of the running maximum small */
@@ -448,6 +490,8 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 for (int s = 0; s <= S; s++)
                     for (int m = 0; m < 8; m++) { ln->xh[s][m] = REB(ln->xh[s][m]); ln->xe[s][m] = REB(ln->xe[s][m]); }
                 for (int x = 0; x < 7; x++) if (ln->A[x] != INT_MIN) ln->A[x] = imax(ln->A[x] - (L16_DELTA << K), imin(ln->A[x], ((L16_LO + 32768) << K) - 1 - (32768 << K)));
+                for (int hf = 0; hf < 2; hf++)
+                    for (int x = 0; x < 7; x++) if (ln->AV[hf][x] != INT_MIN) ln->AV[hf][x] = REB(ln->AV[hf][x]);
             }
         }
         for (int k = 0; k < G; k++)
@@ -468,13 +512,23 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
     }
 #undef TRACK
 #undef REB
+    if (margin > 0 && !bail && !pos_known) again = 1;          /* the pair ends without the cell of its maximum */
     out3[0] = best; out3[1] = best_q; out3[2] = best_t;
     if (stats) { stats[0] = vmin; stats[1] = vmax; stats[2] = bail ? INT_MIN : gmax; stats[3] = bail ? INT_MAX : rmin; }
     free(pq); free(L);
+    if (again && !bail) {           /* started over, on key steps only */
+        agatha_lanes16_margin = 0;
+        const int rc = agatha_model_lanes16(qs, Q, rs, R, pr, G, S, out3, stats);
+        agatha_lanes16_margin = margin;
+        return rc == 0 ? 2 : rc;
+    }
     return bail;
 }
 
-/* kind[k]: 0 = aligned by the int16 model, 1 = ineligible / bailed out (out arrays hold the int32 model's answer) */
+/* kind[k]: 0 = aligned by the int16 model, 1 = ineligible / bailed out (out arrays hold the int32 model's answer),
+ * 2 = aligned by the int16 model after being started over (value steps, agatha_lanes16_set_margin) */
+static int l16_batch_margin = 0;
+void agatha_lanes16_set_margin(int margin) { l16_batch_margin = margin; }
 void agatha_lanes16_batch(const uint8_t *qbatch, const uint8_t *tbatch, const uint32_t *qoff, const uint32_t *toff,
                           const uint32_t *qlen, const uint32_t *tlen, int n, const lm_params_t *pr, int G, int S,
                           int threads, int32_t *score, int32_t *qend, int32_t *tend, int32_t *kind, int32_t *stats4)
@@ -486,6 +540,7 @@ void agatha_lanes16_batch(const uint8_t *qbatch, const uint8_t *tbatch, const ui
 #endif
     for (int k = 0; k < n; k++) {
         int32_t o[3] = {0, 0, 0}, st[4] = {0, 0, INT_MIN, INT_MAX};
+        agatha_lanes16_margin = l16_batch_margin;
         int rc = agatha_model_lanes16((const char *)qbatch + qoff[k], (int)qlen[k], (const char *)tbatch + toff[k],
                                       (int)tlen[k], pr, G, S, o, st);
         if (rc == 1) rc = agatha_model_lanes((const char *)qbatch + qoff[k], (int)qlen[k], (const char *)tbatch + toff[k],

@@ -108,7 +108,7 @@ def lanes_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, G, S, threads=1):
     return out[0], out[1], out[2]
 
 
-def lanes16_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, G, S, threads=1):
+def lanes16_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, G, S, threads=1, value_step_margin=0):
     """CPU emulation of the packed-int16 kernel's arithmetic (no band masks, cut constants, bail-out to int32).
     Returns (score, qend, tend, kind, stats): kind 0 = int16 path, 1 = fell back to the int32 model, -1 = window too
     small; stats = (min rep, max rep, largest out-of-band rep, smallest in-band rep)."""
@@ -118,6 +118,9 @@ def lanes16_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, G, S, threads=1):
     arrs = [np.ascontiguousarray(a, np.uint32) for a in (qoff, toff, qlen, tlen)]
     out = np.zeros((4, n), np.int32)
     st = np.zeros(4, np.int32)
+    # value_step_margin > 0: emulate the kernel's value steps (all but a pair's last `margin` steps only track the values of the
+    # anti-diagonal maxima); kind 2 = the pair had to be started over on key steps
+    lib().agatha_lanes16_set_margin(int(value_step_margin))
     lib().agatha_lanes16_batch(qbuf.ctypes.data, tbuf.ctypes.data, *[a.ctypes.data for a in arrs], n,
                                C.byref(params), int(G), int(S), int(threads),
                                out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data,

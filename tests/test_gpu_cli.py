@@ -259,3 +259,56 @@ def test_cli_batch_larger_than_one_round_of_lane_groups(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert (parse(r.stdout) == np.stack([es, eq, et], axis=1)).all()
     assert len(open(raw).read().split()) == 1
+
+
+@pytest.mark.parametrize("threads,gflag", [(1, []), (2, ["-g", "1"])])
+def test_cli_two_storages_with_batches_larger_than_one_round(tmp_path, threads, gflag):
+    """The CLI's default shape: two streams (storages) per host thread, each holding a batch of more pairs than the int16
+    kernel has lane groups, so two persistent full-chip grids on static schedules are enqueued back to back.  The second
+    grid's workgroups only become resident as the first one's leave; a lane group that waited 50 ms for a neighbour that is
+    not resident would take the pair over (MIG_STOLEN) -- correct, but a cliff: the statistics line of every batch
+    (AGATHA_AMD_RAW_STATS) must show none.  Also run as `-g 1 -n 2` (device selection through gasal_set_device, two host
+    threads = four storages)."""
+    n, a = 9500 * 2 * threads, 9500
+    qs, ts = synth.make_pairs(33, n, lambda r: int(r.integers(300, 900)), 0.03, 0.03, 0.04)
+    f1, f2, raw, stats = tmp_path / "a.fa", tmp_path / "b.fa", tmp_path / "raw.log", tmp_path / "stats.txt"
+    write_fasta(f1, qs, header=">", width=10 ** 9)
+    write_fasta(f2, ts, header=">", width=10 ** 9)
+    P = O.make_params(w=40, z=100)
+    exp = np.stack(O.align_pairs(qs, ts, P, wide=True, threads=8), axis=1)
+    r = subprocess.run([MANUAL, "-p", "-w", "40", "-z", "100", "-a", str(a), "-n", str(threads)] + gflag + [str(f1), str(f2), str(raw)],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, AGATHA_AMD_RAW_STATS=str(stats)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    match_batches(parse(r.stdout), [exp[k:k + a] for k in range(0, n, a)])
+    lines = [l.split() for l in open(stats)]
+    assert len(lines) == 2 * threads == len(open(raw).read().split())
+    assert all(int(l[0]) == a for l in lines)
+    assert sum(int(l[6]) for l in lines) == 0, lines            # no pair was taken over after a time-out
+    assert all(int(l[2]) > 0 for l in lines)                    # and the batches ran on value steps
+
+
+def test_cli_start_positions_of_ultra_long_reads(tmp_path):
+    """`manual -S` on reads of BASELINE's ultra-long shape (~130 kb, band 1500): the backward pass runs without z-drop, and
+    must not arm the range check that z < 0 implies for scores that sink without bound (round 2 refused such batches with
+    AGATHA_AMD_ERANGE although the forward pass had accepted them); also a packed (-k) batch whose sequences overflow the first
+    host page (capacity of packed storages is accounted in packed bytes)."""
+    rng = np.random.default_rng(5)
+    qs, ts = [], []
+    for L in (131000, 128500, 3000):
+        ref = synth.random_seq(rng, L)
+        qs.append(synth.random_seq(rng, 17).tobytes() + ref.tobytes())          # the alignment starts behind the origin
+        ts.append(synth.mutate(rng, ref, 0.03, 0.03, 0.04).tobytes())
+    f1, f2, raw = tmp_path / "a.fa", tmp_path / "b.fa", tmp_path / "raw.log"
+    write_fasta(f1, qs, header=">", width=10 ** 9)
+    write_fasta(f2, ts, header=">", width=10 ** 9)
+    P = O.make_params(w=1500, z=400)
+    es, eq, et = O.align_pairs(qs, ts, P, wide=True, threads=4)
+    xq, xt, _ = O.start_positions(qs, ts, P, eq, et, threads=4)
+    exp = np.stack([es, eq, et, xq, xt], axis=1)
+    for extra in ([], ["-k"]):
+        r = subprocess.run([MANUAL, "-p", "-S", "-w", "1500", "-z", "400"] + extra + [str(f1), str(f2), str(raw)], capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = np.array([[int(f[0])] + [int(x.split("=")[1]) for x in f[1:]] for f in (l.split("\t") for l in r.stdout.strip().splitlines())], np.int64)
+        assert (got == exp).all()
+    assert exp[0, 0] > 100000

@@ -176,6 +176,40 @@ def test_int16_kernel_model_equals_oracle(seed):
     assert fell_back < 10 * 16 // 2
 
 
+@pytest.mark.parametrize("margin", [1, 4, 16])
+def test_value_steps_decide_nothing_but_the_running_maximum(margin):
+    """The int16 kernel's value steps (align16_body.inc, FAST) in the lane model: all but a pair's last `margin` steps only
+    track the VALUES of the anti-diagonal maxima, per lane and half, and rely on the calm test (a lower bound of every
+    anti-diagonal maximum within z of the running maximum, inside its zone, inside the pair) to decide nothing but the
+    running maximum; pairs that meet a step they cannot decide, or end without the cell of their maximum, are started
+    over on key steps (kind 2).  Whatever the margin, the results are the oracle's; clean pairs are never started over
+    with a window of 16 key steps; broken pairs (z-drop) are."""
+    rng = np.random.default_rng(100 + margin)
+    started_over = clean_started_over = 0
+    for trial in range(6):
+        w = int(rng.choice([24, 47, 100, 200, 751]))
+        z = int(rng.choice([-1, 20, 100, 400]))
+        s = int(rng.choice([1, 3, 5]))
+        m, x, q, r = [(2, 4, 4, 2), (1, 4, 6, 2), (2, 3, 5, 1)][int(rng.integers(0, 3))]
+        prm = O.make_params(m, x, q, r, s, z, w)
+        qs, ts = _mixed_pairs(rng, 12, 2500)
+        clean = synth.make_pairs(int(rng.integers(1, 1000)), 6, lambda g: int(g.integers(600, 2500)), 0.03, 0.03, 0.04)
+        qs, ts = qs + clean[0], ts + clean[1]
+        qb, qo, ql = O.make_batch(qs)
+        tb, to, tl = O.make_batch(ts)
+        W = (w + 7) // 8
+        G, S = [c for c in ((16, 2), (16, 4), (16, 6), (32, 4), (32, 6), (64, 4)) if c[0] * c[1] >= W + 1][0]
+        e = O.align_batch(qb, tb, qo, to, ql, tl, prm, wide=True, model=O.MODEL_STEPS, threads=4)
+        sc, qe, te, kind, st = O.lanes16_batch(qb, tb, qo, to, ql, tl, prm, G, S, threads=4, value_step_margin=margin)
+        assert np.array_equal(e[0], sc) and np.array_equal(e[1], qe) and np.array_equal(e[2], te)
+        started_over += int((kind == 2).sum())
+        if z < 0 or z >= 400:                  # (with a small z even a clean pair dips far enough below its maximum)
+            clean_started_over += int((kind[-6:] == 2).sum())
+    assert started_over > 0
+    if margin >= 16:
+        assert clean_started_over == 0
+
+
 def _seq_ops_fixture():
     import json
     d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seq_ops_as_written.json")))

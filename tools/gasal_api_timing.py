@@ -1,0 +1,73 @@
+"""The product's real entry point timed by the reference's own protocol (AGAThA.sh:44,52 + gasal_align.cu:219-236): the CLI
+`agatha_amd/manual -p ...` reads two FASTA files, pushes batches of -a pairs through gasal_aln_async on two streams per host
+thread (-n threads), the library appends every batch's kernel milliseconds to raw.log, and the sum of raw.log is what
+AGAThA.sh averages into time.json.  Used by bench.py (the "gasal_api" object) and as a tool:
+
+    python tools/gasal_api_timing.py [C1|C0] [pairs]        # -a 8192 / 10000, -n 1 / 2; one JSON object per line
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+MANUAL = os.path.join(ROOT, "agatha_amd", "manual")
+
+
+def write_fasta(path, seqs):
+    """The reference's two-line records (test_prog.cpp:94-141): a header whose first character is the op code, one sequence line."""
+    with open(path, "wb") as f:
+        for k, s in enumerate(seqs):
+            f.write(b">" + str(k + 1).encode() + b"\n" + s + b"\n")
+
+
+def run_cli(ref_fa, query_fa, scoring, w, z, a, n_threads, workdir, extra=()):
+    raw = os.path.join(workdir, f"raw_{a}_{n_threads}.log")
+    stats = os.path.join(workdir, f"stats_{a}_{n_threads}.txt")
+    score = os.path.join(workdir, f"score_{a}_{n_threads}.log")
+    for p in (raw, stats):
+        if os.path.exists(p):
+            os.remove(p)
+    cmd = [MANUAL, "-p", "-m", str(scoring["m"]), "-x", str(scoring["x"]), "-q", str(scoring["q"]), "-r", str(scoring["r"]),
+           "-s", "3", "-z", str(z), "-w", str(w), "-a", str(a), "-n", str(n_threads), *extra, ref_fa, query_fa, raw]
+    env = dict(os.environ, AGATHA_AMD_RAW_STATS=stats)
+    t0 = time.time()
+    with open(score, "wb") as out:
+        subprocess.check_call(cmd, stdout=out, env=env)
+    wall = time.time() - t0
+    ms = [float(x) for x in open(raw).read().split()]
+    per_batch = [dict(zip(("pairs", "kernel_ms", "value_wave_steps", "key_wave_steps", "pairs_started_over", "went_back_to_checkpoint", "pairs_taken_over"),
+                          (int(v[0]), float(v[1]), *map(int, v[2:])))) for v in (l.split() for l in open(stats)) if len(v) == 7]
+    return dict(cmd=" ".join(os.path.basename(c) if c.startswith("/") else c for c in cmd), batches=len(ms), kernel_ms_per_batch=[round(x, 3) for x in ms],
+                kernel_ms_sum=sum(ms), wall_s=wall, pairs_taken_over=sum(b["pairs_taken_over"] for b in per_batch), per_batch=per_batch, score_log=score)
+
+
+def time_config(qs, ts, scoring, w, z, combos=((10000, 1),), keep_dir=None):
+    d = keep_dir or tempfile.mkdtemp(prefix="agatha_cli_")
+    ref_fa, query_fa = os.path.join(d, "ref.fasta"), os.path.join(d, "query.fasta")
+    write_fasta(ref_fa, qs); write_fasta(query_fa, ts)
+    out = []
+    for a, n in combos:
+        r = run_cli(ref_fa, query_fa, scoring, w, z, a, n, d)
+        r.update(a=a, n_threads=n, pairs=len(qs))
+        out.append(r)
+    if keep_dir is None:
+        for f in os.listdir(d):
+            os.remove(os.path.join(d, f))
+        os.rmdir(d)
+    return out
+
+
+if __name__ == "__main__":
+    from agatha_amd import workload
+    name = sys.argv[1] if len(sys.argv) > 1 else "C1"
+    gen, scoring, w, z, n0 = {"C1": (workload.cfg_c1, dict(m=2, x=4, q=4, r=2), 751, 400, 10000),
+                              "C0": (workload.cfg_c0, dict(m=2, x=4, q=4, r=2), 751, 400, 20000)}[name]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else n0
+    qs, ts = gen(n=n)
+    for r in time_config(qs, ts, scoring, w, z, combos=((8192, 1), (8192, 2), (10000, 1), (10000, 2))):
+        r.pop("per_batch"); r.pop("score_log")
+        print(json.dumps(dict(config=name, **r)), flush=True)
