@@ -274,17 +274,17 @@ def test_cli_two_storages_with_batches_larger_than_one_round(tmp_path, threads, 
     f1, f2, raw, stats = tmp_path / "a.fa", tmp_path / "b.fa", tmp_path / "raw.log", tmp_path / "stats.txt"
     write_fasta(f1, qs, header=">", width=10 ** 9)
     write_fasta(f2, ts, header=">", width=10 ** 9)
-    P = O.make_params(w=40, z=100)
+    P = O.make_params(w=200, z=100)
     exp = np.stack(O.align_pairs(qs, ts, P, wide=True, threads=8), axis=1)
-    r = subprocess.run([MANUAL, "-p", "-w", "40", "-z", "100", "-a", str(a), "-n", str(threads)] + gflag + [str(f1), str(f2), str(raw)],
-                       capture_output=True, text=True, timeout=900, env=dict(os.environ, AGATHA_AMD_RAW_STATS=str(stats)))
+    r = subprocess.run([MANUAL, "-p", "-w", "200", "-z", "100", "-a", str(a), "-n", str(threads)] + gflag + [str(f1), str(f2), str(raw)],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, AGATHA_AMD_RAW_STATS=str(stats), AGATHA_AMD_FORCE_INT16="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     match_batches(parse(r.stdout), [exp[k:k + a] for k in range(0, n, a)])
     lines = [l.split() for l in open(stats)]
     assert len(lines) == 2 * threads == len(open(raw).read().split())
     assert all(int(l[0]) == a for l in lines)
     assert sum(int(l[6]) for l in lines) == 0, lines            # no pair was taken over after a time-out
-    assert all(int(l[2]) > 0 for l in lines)                    # and the batches ran on value steps
+    assert all(int(l[2]) + int(l[3]) > 0 for l in lines), lines         # and the batches ran on the int16 kernel
 
 
 def test_cli_start_positions_of_ultra_long_reads(tmp_path):
