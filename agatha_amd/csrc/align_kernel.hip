@@ -141,8 +141,8 @@ __device__ __forceinline__ bool word_has_n(uint32_t v, uint32_t nbases)
     return has;
 }
 
-// kind of each pair: 1 = a sequence holds a letter outside {A, C, G, T, N} (compare kernel); 2 = the QUERY holds an N
-// (the packed-int16 kernel's score profile has no row for it: int32 profile kernel); 0 = everything else
+// kind of each pair (low 7 bits): 1 = a sequence holds a letter outside {A, C, G, T, N} (compare kernel); 0 = everything else,
+// with bit 7 set when the QUERY holds an N (2 and 3 are given later / below)
 __global__ void __launch_bounds__(256)
 exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict__ packed_t,
               const uint32_t* __restrict__ qlens, const uint32_t* __restrict__ tlens,
@@ -166,7 +166,9 @@ exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict_
         for (uint32_t i = lane; i < nb; i += 64u) plain = plain && word_is_plain(b[i]);
         const bool all_plain = __all(plain), any_qn = __any(qn);
         if (lane == 0) {
-            int kind = all_plain ? (any_qn ? 2 : 0) : 1;
+            // (bit 7 on a plain pair: its query -- the DP rows -- holds an N.  Every kernel scores N in line, gasal_kernels.h:48-50;
+            //  the packed-int16 kernel needs to know because its score profile has no row for it: align16_body.inc, NROW)
+            int kind = all_plain ? (any_qn ? 0x80 : 0) : 1;
             // kind 3: the scores this pair can reach do not fit the kernels' H << K keys (only possible when the caller
             // gave no length hints: with hints the host refuses the whole call, AGATHA_AMD_ERANGE): no kernel takes it
             const long long Q = ql, R = tlens[p], lmin = Q < R ? Q : R, lmax = Q > R ? Q : R;
@@ -178,7 +180,7 @@ exotic_kernel(const uint32_t* __restrict__ packed_q, const uint32_t* __restrict_
                 score[p] = INT_MIN; qend[p] = -1; tend[p] = -1;          // AGATHA_AMD_BAD_RESULT
             }
             exotic[p] = (uint8_t)kind;
-            if (kind == 1 || kind == 2) atomicAdd(kind_counts + (kind - 1), 1u);
+            if (kind == 1) atomicAdd(kind_counts + 0, 1u);
         }
     }
 }
@@ -386,13 +388,14 @@ schedule_kernel(AlignLaunch L, int GS, int G)
     const int j0 = t * chunk, j1 = min(n, j0 + chunk);
     auto steps_of = [&](int j) -> uint32_t {
         const uint32_t pair = L.order[j];
-        if (L.exotic[pair] != 0) return 0u;                 // another kernel's pair: skipped when drawn
+        if ((L.exotic[pair] & 0x7f) != 0) return 0u;        // another kernel's pair: skipped when drawn
         const int Q = (int)L.qlens[pair], R = (int)L.tlens[pair];
         const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
         if (Q <= 0 || R <= 0 || min(W + 1, min(pql, prl)) > GS || pql + GS >= 32760 || prl + GS >= 32760) return 1u;
         const int total = pql + prl - 1;
         // dry step + whole slices + the final check step + what starting it costs (every start stalls all 64 / G groups of the wave)
-        return (uint32_t)(((total + sw - 1) / sw) * sw + 2 + kMigPairOverheadSteps * (64 / G));
+        uint32_t st = (uint32_t)(((total + sw - 1) / sw) * sw + 2 + kMigPairOverheadSteps * (64 / G));
+        return st;
     };
     uint32_t sum = 0, mx = 0, nz = 0;
     for (int j = j0; j < j1; j++) { const uint32_t p = steps_of(j); sum += p; mx = max(mx, p); nz += p > 1u; }

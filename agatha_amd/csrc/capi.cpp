@@ -40,7 +40,7 @@ DebugOption g_opts[] = {
     {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts)
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
     {"fast_margin", "AGATHA_AMD_FAST_MARGIN", {16}},   // int16 kernel: value steps except in a pair's last n steps; 0: key steps only
-    {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {4096}},   // int16 kernel: pairs of at least this many steps take checkpoints (0: none do)
+    {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {2048}},   // int16 kernel: pairs of at least this many steps take checkpoints (0: none do)
 };
 enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FAST_MARGIN, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
@@ -532,7 +532,7 @@ int agatha_amd_pair_kinds(void* stream, const void* d_workspace, uint32_t n_alns
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { free(h); return hip_fail(e, "agatha_amd_pair_kinds"); }
     counts[0] = counts[1] = counts[2] = 0;
-    for (uint32_t k = 0; k < n_alns; k++) if (h[k] < 3) counts[h[k]]++;
+    for (uint32_t k = 0; k < n_alns; k++) if ((h[k] & 0x7f) < 3) counts[h[k] & 0x7f]++;
     free(h);
     return 0;
 }

@@ -21,7 +21,7 @@ struct AlignLaunch {
     const uint32_t *packed_q, *packed_t, *qlens, *tlens, *qoffs, *toffs, *order;
     int n;
     unsigned int* queue;
-    uint8_t* exotic;               // per pair kind: 0 = plain, 1 = holds letters outside ACGTN (compare kernel),
+    uint8_t* exotic;               // per pair kind (low 7 bits; bit 7 = plain pair whose query holds an N): 0 = plain, 1 = holds letters outside ACGTN (compare kernel),
                                    // 2 = abandoned by the packed-int16 kernel (int32 profile kernel takes it),
                                    // 3 = scores out of the kernels' range (no kernel takes it: AGATHA_AMD_BAD_RESULT)
     int ncand;                     // candidates for the kind-0 pairs, in launch order

@@ -120,3 +120,19 @@ def cfg_c4(n=20000, seed=0xA6A70004, lo=1000, hi=100000):
         qs.append(ref.tobytes())
         ts.append(read.tobytes())
     return qs, ts
+
+
+def add_n_runs(seqs, frac, seed=1, lo=50, hi=1000):
+    """A run of N (lo..hi bases, uniform position) in a fraction of the sequences: what reference-genome pieces look like
+    around assembly gaps.  Returns a new list."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for s in seqs:
+        if rng.random() < frac and len(s) > 8:
+            a = np.frombuffer(s, dtype=np.uint8).copy()
+            n = int(min(rng.integers(lo, hi + 1), a.size - 1))
+            at = int(rng.integers(0, a.size - n + 1))
+            a[at:at + n] = ord("N")
+            s = a.tobytes()
+        out.append(s)
+    return out

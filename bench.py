@@ -26,9 +26,16 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # int32 VALU roof: v_max/v_max3/v_add3/v_cndmask/v_cmp sustain ~15 lanes/clk/SIMD on this chip (4 cycles per wave64
 # instruction; tools/microbench/valu_rate.hip, profiles/r01_v1/valu_issue_rate_microbench.txt) -> 256 CU x 4 SIMD x 16 x 2.4 GHz
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# the guide's figure for the same units (MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on a SIMD): twice the
+# above.  Only homogeneous v_add / v_xor / v_mov streams come near it on this chip (profiles/r03_v0/valu_rate.txt: every
+# instruction this kernel is made of -- v_pk_max/min/sub_u16, v_add_u16_sdwa, v_mad_u32_u16, v_max3 -- sustains 4 cycles);
+# quoted beside the measured roof so that a reader sees both
+VALU_GUIDE_PEAK_TOPS = 2 * VALU_PEAK_TOPS
 # algorithmic VALU lane-ops of one DP cell incl. the anti-diagonal maximum: 11 int32 ops per cell in the
 # int32 kernel; 10 packed ops per TWO cells in the packed-int16 kernel (2 score adds, 4 max, 1 sub, 2 key mads, 1 max3)
 OPS_PER_CELL = {"int32": 11.0, "int16": 5.0}
+# ... and on the int16 kernel's value steps (round 3) the maximum costs one packed instruction instead of three: 8 per two cells
+OPS_PER_CELL_VALUE_STEPS = 4.0
 
 
 # BASELINE.json's workload shapes; "pairs" is the size that fits one GPU comfortably (C2 is 100 k pairs on 8
@@ -117,6 +124,7 @@ def main():
     ap.add_argument("--config", default="C1", choices=sorted(CONFIGS), help="workload shape of BASELINE.json (default C1 = configs[1], the headline)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank aligns its own batch; strong: ONE batch, LPT-sharded over the ranks, results gathered")
+    ap.add_argument("--n-run-frac", type=float, default=0.0, help="fraction of the DP-row sequences (file 1: reference pieces) that carry a run of N (50-1000 bases)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gasal-api", action="store_true", help="skip the timing of the CLI / GASAL API by the reference's raw.log protocol")
     a = ap.parse_args()
@@ -156,6 +164,8 @@ def main():
     # weak scaling: every rank has its own batch (own seed); strong scaling: every rank builds the SAME batch and keeps its
     # share of the LPT partition by nominal cells (agatha_amd/shard.py) -- no data-path exchange, results gathered at the end
     qs, ts = getattr(workload, cfg["gen"])(n=a.pairs, seed=0xA6A70000 + int(a.config[1]) + (0 if strong else rank))
+    if a.n_run_frac > 0:
+        qs = workload.add_n_runs(qs, a.n_run_frac, seed=7 + rank)
     qb, qo, ql = workload.make_batch(qs)
     tb, to, tl = workload.make_batch(ts)
     del qs, ts
@@ -277,7 +287,7 @@ def main():
             "vs_baseline": None,
             "dtype": kind,
             "data": "synthetic",
-            "config": {"workload": f"{a.config}: {a.pairs} {cfg['text']}, " + ("ONE batch sharded over the GPUs (LPT by nominal cells)" if strong else "per GPU") +
+            "config": {"workload": f"{a.config}: {a.pairs} {cfg['text']}, " + (f"{a.n_run_frac:.0%} of the DP-row sequences with a run of N, " if a.n_run_frac > 0 else "") + ("ONE batch sharded over the GPUs (LPT by nominal cells)" if strong else "per GPU") +
                                    f", m{cfg['scoring']['m']} x{cfg['scoring']['x']} q{cfg['scoring']['q']} r{cfg['scoring']['r']} w{W_BAND} z{Z} s3 "
                                    f"(BASELINE.json configs[{int(a.config[1])}])",
                        "pairs_per_gpu": b.n, "shard_imbalance_max_over_mean": imbalance, "strong_scaling_check": strong_check, "lanes_per_pair": Gd, "slots_per_lane": Sd, "kernel": kname,
@@ -300,10 +310,16 @@ def main():
                               "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
                               "frac": cells * OPS_PER_CELL[kind] / kernel_ms / 1e9 / VALU_PEAK_TOPS,
                               "ops_per_cell": OPS_PER_CELL[kind],
+                              "frac_vs_guide_2cycle_issue": cells * OPS_PER_CELL[kind] / kernel_ms / 1e9 / VALU_GUIDE_PEAK_TOPS,
+                              "frac_at_value_step_count": (cells * OPS_PER_CELL_VALUE_STEPS / kernel_ms / 1e9 / VALU_PEAK_TOPS) if kind == "int16" else None,
+                              "peak_source": "measured: profiles/r03_v0/valu_rate.txt (4 cycles per wave64 instruction for every op of the kernel); "
+                                             "frac_vs_guide_2cycle_issue prices the same ops against the guide's 2-cycle issue",
                               "issued_lane_ops_per_cell": (issued * 64.0 / cells) if issued else None,
                               "lds_bank_conflict_cycles": conflicts,
                               "note": "lane-ops the recurrence itself needs per cell x cells/s over the measured VALU issue "
-                                      "rate of the chip; the int16 kernel does two cells per packed lane-op"},
+                                      "rate of the chip; the int16 kernel does two cells per packed lane-op.  ops_per_cell keeps "
+                                      "round 2's count (10 per cell pair with H : column keys) so that rounds compare; value steps "
+                                      "need 8 per cell pair (frac_at_value_step_count)"},
         }
         if world == 1 and not a.no_gasal_api and a.config in ("C0", "C1"):
             # The same batch through the product's real entry point, by the reference's own protocol (AGAThA.sh:44,52: `manual -p`,

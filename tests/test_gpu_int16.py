@@ -212,8 +212,8 @@ def test_pairs_the_int16_kernel_hands_back(eng):
 
 
 def test_n_in_query_and_other_letters_are_routed(eng):
-    """N in the query has no row in the int16 kernel's score profile (int32 profile kernel takes the pair); letters
-    outside ACGTN go to the compare kernel; N in the reference stays on the int16 kernel."""
+    """N on either side stays on the int16 kernel (N in the query -- the DP rows -- through the block variant that knows N
+    rows, on key steps); letters outside ACGTN go to the compare kernel."""
     rng = np.random.default_rng(4)
     qs, ts = [], []
     for k in range(30):
@@ -227,16 +227,50 @@ def test_n_in_query_and_other_letters_are_routed(eng):
         if k % 5 == 4:
             rd[rng.integers(0, rd.size)] = ord("R")
         qs.append(ref.tobytes()); ts.append(rd.tobytes())
-    got, exp = _run(eng, qs, ts, BASE)
+    got, exp, kinds = _run_with_kinds(eng, qs, ts, BASE)
     assert _same(got, exp)
+    assert kinds[1] == 6 and kinds[2] == 0          # the six pairs with an R: compare kernel; nothing to the int32 profile kernel
+
+
+@pytest.mark.parametrize("p", [BASE, dict(BASE, w=100, z=60), dict(m=1, x=4, q=6, r=2, s=1, z=400, w=500), dict(BASE, w=1500)])
+def test_n_runs_in_the_query_on_the_int16_kernel(eng, p):
+    """N in the DP-row sequence (the reference scores it in line, gasal_kernels.h:48-50; `AGAThA.sh:44` passes ref.fasta first, so
+    the rows are reference-genome pieces, where N runs live): runs of N of every length and phase against the 8-row blocks,
+    at the start, in the middle and at the ragged end of the query, with N in the target as well, on the throughput and the
+    latency shapes.  The pairs stay on the int16 kernel (no take-over) and the wave returns to value steps behind a run."""
+    rng = np.random.default_rng(17)
+    qs, ts = [], []
+    for k in range(90):
+        ref = WL.random_seq(rng, int(rng.integers(300, 5000)))
+        rd = WL.mutate(rng, ref, 0.03, 0.03, 0.04).copy()
+        ref = ref.copy()
+        if k % 6 != 5:
+            for _ in range(int(rng.integers(1, 4))):
+                a = int(rng.integers(0, ref.size)); n = int(rng.choice([1, 2, 7, 8, 9, 40, 300]))
+                ref[a:a + n] = ord("N")
+        if k % 4 == 0:
+            ref[-int(rng.integers(1, 12)):] = ord("N")          # N up to the ragged end of the query
+        if k % 7 == 0:
+            rd[rng.random(rd.size) < 0.01] = ord("N")
+        qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    got, exp, st, kinds = _run_stats(eng, qs, ts, p)
+    assert _same(got, exp)
+    assert kinds[1] == 0 and kinds[2] == 0
+    assert st[0] > 0 and st[1] > 0                  # value steps, and key steps where N rows were in flight
+    agatha_amd.set_debug_option("force_choice", 1)            # the latency shape
+    try:
+        got, exp, st, kinds = _run_stats(eng, qs, ts, p)
+        assert _same(got, exp) and kinds[2] == 0
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
 
 
 @pytest.mark.parametrize("n", [4100, 5000, 8000, 8185, 8192, 8200, 9000, 12288, 12300, 15000, 16384, 16400])
 def test_first_round_dealt_to_the_workgroups(eng, n):
     """With a full grid (8192 lane groups for a narrow band) and between 1 and 2 rounds of pairs the int16 kernel deals
     the first round to the workgroups by formula (which waves share a SIMD; two formulas, below and above 1.5 rounds)
-    and takes the rest from the queue; pairs the kernel must skip (N in the query, other letters) sit in the dealt range
-    as well.  16 400 pairs: plain queue.  Below one round, with more workgroups than CUs, everything is dealt (the CUs
+    and takes the rest from the queue; pairs the kernel must skip (other letters) and pairs with an N in the query sit in the
+    dealt range as well.  16 400 pairs: plain queue.  Below one round, with more workgroups than CUs, everything is dealt (the CUs
     with one workgroup take the longest chunks)."""
     rng = np.random.default_rng(n)
     qs, ts = [], []
@@ -247,7 +281,7 @@ def test_first_round_dealt_to_the_workgroups(eng, n):
             rd = WL.random_seq(rng, 1)
         ref, rd = ref.copy(), rd.copy()
         if k % 97 == 5:
-            ref[rng.integers(0, ref.size)] = ord("N")          # N in the query (file 1): int32 profile kernel
+            ref[rng.integers(0, ref.size)] = ord("N")          # N in the query (file 1): stays here, on key steps
         if k % 89 == 7:
             rd[rng.integers(0, rd.size)] = ord("R")            # other letter: compare kernel
         qs.append(ref.tobytes()); ts.append(rd.tobytes())
@@ -258,7 +292,7 @@ def test_first_round_dealt_to_the_workgroups(eng, n):
     finally:
         agatha_amd.set_debug_option("force_choice", -1)
     assert _same(got, exp)
-    assert int(kinds[1]) > 0 and int(kinds[2]) > 0
+    assert int(kinds[1]) > 0 and int(kinds[2]) == 0
 
 
 def test_first_round_dealt_in_the_latency_shape(eng):
