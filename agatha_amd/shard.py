@@ -46,13 +46,15 @@ def lpt_partition(cost, world):
 
 def take_pairs(qbuf, tbuf, qoff, toff, qlen, tlen, idx):
     """Sub-batch (GASAL wire format) holding the pairs `idx`, re-packed contiguously."""
+    idx = np.asarray(idx, np.int64)
+
     def side(buf, off, ln):
+        # one gather over the whole side: byte j of the output comes from (source offset - destination offset of its pair) + j
         sizes = (np.asarray(ln, np.int64)[idx] + 7) // 8 * 8
-        noff = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint32) if len(idx) else np.zeros(0, np.uint32)
-        out = np.empty(int(sizes.sum()), np.uint8)
-        for k, i in enumerate(idx):
-            out[noff[k]:noff[k] + sizes[k]] = buf[off[i]:off[i] + sizes[k]]
-        return out, noff, np.asarray(ln, np.uint32)[idx]
+        noff = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64) if len(idx) else np.zeros(0, np.int64)
+        total = int(sizes.sum())
+        src = np.repeat(np.asarray(off, np.int64)[idx] - noff, sizes) + np.arange(total, dtype=np.int64)
+        return np.asarray(buf)[src], noff.astype(np.uint32), np.asarray(ln, np.uint32)[idx]
     qb, qo, ql = side(qbuf, qoff, qlen)
     tb, to, tl = side(tbuf, toff, tlen)
     return qb, tb, qo, to, ql, tl

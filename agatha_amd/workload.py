@@ -136,3 +136,85 @@ def add_n_runs(seqs, frac, seed=1, lo=50, hi=1000):
             s = a.tobytes()
         out.append(s)
     return out
+
+
+# ---- the same workload shapes, generated in CHUNKS of consecutive pairs with a random stream per chunk, for the strong-scaling
+# ---- form of the bench: a rank only generates the chunks it owns (bench.py --scaling strong, agatha_amd/shard.py).  A chunk's
+# ---- pairs are made with whole-array operations (all reference bases of the chunk at once, one pass of the error channel).
+CHUNK = 64
+_LEN_LAWS = {
+    "cfg_c0": lambda rng, n: np.clip(np.rint(rng.normal(3000, 1000, n)), 200, 8000),
+    "cfg_c1": lambda rng, n: np.clip(np.rint(rng.normal(10000, 1000, n)), 8000, 12000),
+    "cfg_c2": lambda rng, n: rng.integers(15000, 20001, n),
+    "cfg_c3": lambda rng, n: np.maximum(1000, np.rint(rng.normal(100000, 10000, n))),
+}
+_CHANNELS = {"cfg_c0": (0.04, 0.03, 0.03), "cfg_c1": (0.03, 0.03, 0.04), "cfg_c2": (0.002, 0.004, 0.004), "cfg_c3": (0.03, 0.03, 0.04)}
+
+
+def chunked_lengths(gen, n, seed):
+    """Reference lengths of all n pairs (cheap: one draw per pair), identical on every rank."""
+    return _LEN_LAWS[gen](np.random.default_rng([seed, 0x1e47]), n).astype(np.int64)
+
+
+def chunked_pairs(gen, seed, lens, chunk_ids):
+    """The pairs of the given chunks (CHUNK consecutive pairs each) in the GASAL wire format:
+    (qbuf, tbuf, qoff, toff, qlen, tlen, pair ids)."""
+    sub, ins, dele = _CHANNELS[gen]
+    n = len(lens)
+    def one(c):
+        lo, hi = int(c) * CHUNK, min(n, (int(c) + 1) * CHUNK)
+        L = lens[lo:hi]
+        rng = np.random.default_rng([seed, 0xc4a9, int(c)])
+        total = int(L.sum())
+        ref = _ACGT[rng.integers(0, 4, size=total, dtype=np.uint8)]
+        u = rng.random(total, dtype=np.float32)
+        keep = u >= dele
+        is_sub = keep & (u < dele + sub)
+        base = ref.copy()
+        ns = int(is_sub.sum())
+        if ns:
+            base[is_sub] = _ACGT[(np.searchsorted(_ACGT, base[is_sub]) + rng.integers(1, 4, size=ns)) % 4]
+        is_ins = rng.random(total, dtype=np.float32) < ins
+        ins_base = _ACGT[rng.integers(0, 4, size=total, dtype=np.uint8)]
+        cnt = is_ins.astype(np.int64) + keep.astype(np.int64)
+        pos = np.cumsum(cnt) - cnt
+        read = np.empty(int(cnt.sum()), np.uint8)
+        read[pos[is_ins]] = ins_base[is_ins]
+        read[(pos + is_ins)[keep]] = base[keep]
+        starts = np.concatenate([[0], np.cumsum(L)[:-1]])
+        rl = np.add.reduceat(cnt, starts)
+        return (ref, L), (read, rl), L, np.maximum(rl, 1), np.arange(lo, hi, dtype=np.int64)      # (an empty read gets one base, as in make_pairs)
+
+    # numpy releases the GIL in these array passes: a few threads make a rank's shard in a fraction of the time
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    chunk_ids = list(chunk_ids)
+    workers = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4, len(chunk_ids)))
+    with ThreadPoolExecutor(workers) as ex:
+        done = list(ex.map(one, chunk_ids))
+    qparts = [d[0] for d in done]; tparts = [d[1] for d in done]
+    ql = [d[2] for d in done]; tl = [d[3] for d in done]; ids = [d[4] for d in done]
+
+    def assemble(parts, lens_true):
+        lt = np.concatenate(lens_true).astype(np.int64)
+        sizes = (lt + 7) // 8 * 8
+        off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        buf = np.full(int(sizes.sum()), ord("N"), np.uint8)
+        k = 0
+        for flat, raw in parts:             # one slice copy per sequence (no index arrays of the batch's size)
+            src = 0
+            for r in raw.tolist():
+                if r:
+                    buf[off[k]:off[k] + r] = flat[src:src + r]
+                else:
+                    buf[off[k]] = ord("A")
+                src += r
+                k += 1
+        return buf, off.astype(np.uint32), lt.astype(np.uint32)
+
+    if not qparts:
+        z8, z32 = np.zeros(0, np.uint8), np.zeros(0, np.uint32)
+        return z8, z8, z32, z32, z32, z32, np.zeros(0, np.int64)
+    qb, qo, qlen = assemble(qparts, ql)
+    tb, to, tlen = assemble(tparts, tl)
+    return qb, tb, qo, to, qlen, tlen, np.concatenate(ids)

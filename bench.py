@@ -163,25 +163,49 @@ def main():
 
     # weak scaling: every rank has its own batch (own seed); strong scaling: every rank builds the SAME batch and keeps its
     # share of the LPT partition by nominal cells (agatha_amd/shard.py) -- no data-path exchange, results gathered at the end
-    qs, ts = getattr(workload, cfg["gen"])(n=a.pairs, seed=0xA6A70000 + int(a.config[1]) + (0 if strong else rank))
-    if a.n_run_frac > 0:
-        qs = workload.add_n_runs(qs, a.n_run_frac, seed=7 + rank)
-    qb, qo, ql = workload.make_batch(qs)
-    tb, to, tl = workload.make_batch(ts)
-    del qs, ts
     from agatha_amd import shard
-    full = (qb, tb, qo, to, ql, tl)
+    seed = 0xA6A70000 + int(a.config[1]) + (0 if strong else rank)
     mine = None
     imbalance = None
-    if strong:
-        cost = shard.nominal_cells(ql, tl, W_BAND)
-        parts = shard.lpt_partition(cost, world)
-        loads = np.array([int(cost[p].sum()) for p in parts], np.float64)
-        imbalance = float(loads.max() / loads.mean())
-        mine = parts[rank]
-        total_batch_cells, total_batch_pairs = float(cost.sum()), float(len(ql))
-        qb, tb, qo, to, ql, tl = shard.take_pairs(qb, tb, qo, to, ql, tl, mine)
+    full = None
+    chunked = strong and cfg["gen"] in workload._LEN_LAWS
+    t_gen = time.perf_counter()
+    if chunked:
+        # ONE batch of a.pairs pairs, made in chunks of 64 consecutive pairs with a random stream per chunk: every rank draws the
+        # lengths of all pairs (one number each), deals the CHUNKS by LPT over their nominal cells, and generates only its own
+        lens = workload.chunked_lengths(cfg["gen"], a.pairs, seed)
+        _, ins_, del_ = workload._CHANNELS[cfg["gen"]]
+        est = shard.nominal_cells(lens, np.rint(lens * (1.0 + ins_ - del_)).astype(np.int64), W_BAND)
+        nch = (a.pairs + workload.CHUNK - 1) // workload.CHUNK
+        chunk_cost = np.add.reduceat(est, np.arange(0, a.pairs, workload.CHUNK))
+        parts = shard.lpt_partition(chunk_cost, world)
+        qb, tb, qo, to, ql, tl, mine = workload.chunked_pairs(cfg["gen"], seed, lens, parts[rank])
+        total_batch_pairs = float(a.pairs)
+    else:
+        qs, ts = getattr(workload, cfg["gen"])(n=a.pairs, seed=seed)
+        if a.n_run_frac > 0:
+            qs = workload.add_n_runs(qs, a.n_run_frac, seed=7 + rank)
+        qb, qo, ql = workload.make_batch(qs)
+        tb, to, tl = workload.make_batch(ts)
+        del qs, ts
+        full = (qb, tb, qo, to, ql, tl)
+        if strong:          # (shapes without a chunked generator: every rank builds the whole batch and keeps its share)
+            cost = shard.nominal_cells(ql, tl, W_BAND)
+            parts = shard.lpt_partition(cost, world)
+            mine = parts[rank]
+            total_batch_pairs = float(len(ql))
+            qb, tb, qo, to, ql, tl = shard.take_pairs(qb, tb, qo, to, ql, tl, mine)
+    t_gen = time.perf_counter() - t_gen
     cells = int(shard.nominal_cells(ql, tl, W_BAND).sum())
+    if strong:
+        loads = np.zeros(world, np.float64)
+        loads[rank] = cells
+        if use_dist:
+            lt_ = torch.from_numpy(loads).cuda()
+            dist.all_reduce(lt_)
+            loads = lt_.cpu().numpy()
+        imbalance = float(loads.max() / loads.mean())
+        total_batch_cells = float(loads.sum())
     abytes = algorithmic_bytes(ql, tl)
 
     b = eng.batch(qb, tb, qo, to, ql, tl)
@@ -206,7 +230,7 @@ def main():
         if i is not None:
             eng.set_kernel_events(None, None)
         if use_dist and strong:
-            return shard.gather_results_tensor(res_t, idx_t, len(full[4]), dist, torch)     # RCCL: 16 B per pair, input order restored
+            return shard.gather_results_tensor(res_t, idx_t, a.pairs, dist, torch)     # RCCL: 16 B per pair, input order restored
         if use_dist:
             dist.all_gather_into_tensor(gathered, res_t)       # RCCL: 12 B per pair, the only exchange
         else:
@@ -241,11 +265,19 @@ def main():
     if strong:
         total_cells, total_pairs = total_batch_cells, total_batch_pairs
         if use_dist and rank == 0 and last is not None:
-            # rank 0 aligns the WHOLE batch alone once (untimed) and compares it with what the N ranks gathered
-            ref = eng.align_host_batch(*full, scores)
+            # rank 0 aligns the batch alone once more (untimed) -- all of it, or 32 chunks spread over it when it was made in
+            # chunks -- and compares with what the N ranks gathered
             got = last.cpu().numpy()
-            same = int(sum(int(all(int(ref[j][i]) == int(got[j][i]) for j in range(3))) for i in range(len(full[4]))))
-            strong_check = f"{same}/{len(full[4])} pairs identical to the same batch aligned on one GPU"
+            if chunked:
+                pick = np.unique(np.linspace(0, nch - 1, num=min(nch, 32)).astype(np.int64))
+                sb = workload.chunked_pairs(cfg["gen"], seed, lens, pick)
+                ref, ids_ = eng.align_host_batch(*sb[:6], scores), sb[6]
+                same = int(sum(int(all(int(ref[j][k]) == int(got[j][i]) for j in range(3))) for k, i in enumerate(ids_)))
+                strong_check = f"{same}/{len(ids_)} pairs (32 chunks spread over the batch) identical to the same pairs aligned on one GPU"
+            else:
+                ref = eng.align_host_batch(*full, scores)
+                same = int(sum(int(all(int(ref[j][i]) == int(got[j][i]) for j in range(3))) for i in range(len(full[4]))))
+                strong_check = f"{same}/{len(full[4])} pairs identical to the same batch aligned on one GPU"
 
     kinds = b.pair_kinds(stream)            # how the last step's pairs were routed between the kernels
     sched = b.schedule_info(stream)         # (static preemptive schedule used, steps per lane group, lane groups used)
@@ -290,7 +322,7 @@ def main():
             "config": {"workload": f"{a.config}: {a.pairs} {cfg['text']}, " + (f"{a.n_run_frac:.0%} of the DP-row sequences with a run of N, " if a.n_run_frac > 0 else "") + ("ONE batch sharded over the GPUs (LPT by nominal cells)" if strong else "per GPU") +
                                    f", m{cfg['scoring']['m']} x{cfg['scoring']['x']} q{cfg['scoring']['q']} r{cfg['scoring']['r']} w{W_BAND} z{Z} s3 "
                                    f"(BASELINE.json configs[{int(a.config[1])}])",
-                       "pairs_per_gpu": b.n, "shard_imbalance_max_over_mean": imbalance, "strong_scaling_check": strong_check, "lanes_per_pair": Gd, "slots_per_lane": Sd, "kernel": kname,
+                       "pairs_per_gpu": b.n, "host_seconds_to_make_the_rank0_batch": round(t_gen, 2), "shard_imbalance_max_over_mean": imbalance, "strong_scaling_check": strong_check, "lanes_per_pair": Gd, "slots_per_lane": Sd, "kernel": kname,
                        "int32_fallback_kernel": f"agatha::align_kernel<{G},{S}>",
                        "pairs_plain_other_letters_int32_takeover_rank0": list(kinds),
                        "preemptive_schedule_rank0": {"used": sched[0], "steps_per_lane_group": sched[1], "lane_groups": sched[2]},

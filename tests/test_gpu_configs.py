@@ -48,13 +48,67 @@ def test_c2_hifi_band500_both_scorings(eng):
     assert got[0].max() > 32767
 
 
+def _run_batch(eng, qs, ts, **p):
+    """like _run, plus (kernel choice, schedule info, step statistics)"""
+    import agatha_amd
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
+        got = [b.res_host[j].copy() for j in range(3)]
+        info = (b.kernel_choice(), b.schedule_info(), b.step_stats(), b.pair_kinds())
+    finally:
+        b.free()
+    return (qb, tb, qo, to, ql, tl), got, info
+
+
+def test_c2_at_the_size_of_one_gpu_share(eng):
+    """C2 at 9 000 pairs (BASELINE: 100 k over 8 GPUs): more pairs than the <16, 2> shape has lane groups, so the static
+    schedule runs on HiFi shapes inside the suite -- pairs suspended by one lane group and resumed by another, value steps,
+    checkpoints (4 400 steps per pair); 500 pairs spread over the batch against the oracle, the rest through determinism."""
+    qs, ts = synth.cfg_c2(n=9000)
+    p = dict(m=1, x=4, q=6, r=2, s=3, z=400, w=500)
+    batch, got, (choice, sched, st, kinds) = _run_batch(eng, qs, ts, **p)
+    assert choice == ("int16", 16, 4) and sched[0]
+    assert st[0] > 10 * st[1] > 0 and kinds[2] == 0
+    k = np.sort(np.random.default_rng(2).choice(9000, 500, replace=False))
+    sb = O.make_batch([qs[i] for i in k]), O.make_batch([ts[i] for i in k])
+    exp = O.align_batch(sb[0][0], sb[1][0], sb[0][1], sb[1][1], sb[0][2], sb[1][2], O.make_params(**p), wide=True,
+                        model=O.MODEL_SLICES, threads=16)
+    assert all((np.asarray(a)[k] == b).all() for a, b in zip(got, exp))
+    _, again, _ = _run_batch(eng, qs, ts, **p)
+    assert all((a == b).all() for a, b in zip(got, again))
+
+
 def test_c3_ultralong_band1500(eng):
-    qs, ts = synth.cfg_c3(n=16)
+    """64 pairs of ~100 kb at band 1500: the device picks the shape that puts one pair on two cooperating waves, and with 64
+    pairs on 1024 workgroup slots every pair... runs alone; the queue of that shape is drawn from in the test below"""
+    qs, ts = synth.cfg_c3(n=64)
     p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=1500)
-    batch, got = _run(eng, qs, ts, **p)
-    assert eng.last_config() == (64, 3)
-    assert max(len(q) for q in qs) > 65536 or max(len(q) for q in qs) > 32768
-    _check(batch, got, **p)
+    batch, got, (choice, sched, st, kinds) = _run_batch(eng, qs, ts, **p)
+    assert choice == ("int16", 128, 2) and kinds[2] == 0
+    assert max(len(q) for q in qs) > 65536
+    _check(batch, got, threads=16, **p)
+
+
+def test_c3_shape_draws_from_its_queue(eng):
+    """The two-wave shape with more pairs than workgroups (1 100 pairs of 13-15 kb at band 1500 on 1024 workgroups: the last ones
+    come from the queue), several workgroups per CU (the waves of a pair drift apart in time), scores that move the base."""
+    import agatha_amd
+    qs, ts = synth.make_pairs(77, 1100, lambda r: int(r.integers(13000, 15000)), 0.03, 0.03, 0.04)
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=1500)
+    agatha_amd.set_debug_option("force_choice", 1)
+    try:
+        batch, got, (choice, sched, st, kinds) = _run_batch(eng, qs, ts, **p)
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
+    assert choice == ("int16", 128, 2) and kinds[2] == 0 and st[2] == 0
+    k = np.sort(np.random.default_rng(3).choice(1100, 300, replace=False))
+    sb = O.make_batch([qs[i] for i in k]), O.make_batch([ts[i] for i in k])
+    exp = O.align_batch(sb[0][0], sb[1][0], sb[0][1], sb[1][1], sb[0][2], sb[1][2], O.make_params(**p), wide=True,
+                        model=O.MODEL_SLICES, threads=16)
+    assert all((np.asarray(a)[k] == b).all() for a, b in zip(got, exp))
 
 
 def test_c4_mixed_lengths_heavy_zdrop(eng):
@@ -85,14 +139,11 @@ def test_c1_full_batch_properties(eng):
     pick = np.sort(rng.choice(10000, 600, replace=False))
     _, sub = _run(eng, [qs[i] for i in pick], [ts[i] for i in pick], **p)       # same pairs in a different batch
     assert all((a[pick] == b).all() for a, b in zip(got, sub))
-    # 1 000 of the 10 000 pairs against the block-granular oracle (the restatement of the reference kernel, not the
-    # exact-band port), spread over the whole batch: they ran on a static schedule, i.e. some of them were suspended by one
-    # lane group and resumed by another
-    k = np.sort(rng.choice(10000, 1000, replace=False))
-    sb = O.make_batch([qs[i] for i in k]), O.make_batch([ts[i] for i in k])
-    exp = O.align_batch(sb[0][0], sb[1][0], sb[0][1], sb[1][1], sb[0][2], sb[1][2], O.make_params(**p), wide=True,
-                        model=O.MODEL_SLICES, threads=16)
-    assert all((a[k] == b).all() for a, b in zip(got, exp))
+    # ALL 10 000 pairs against the block-granular oracle (the restatement of the reference kernel, not the exact-band port):
+    # they ran on a static schedule, i.e. most lane groups suspended one pair and resumed another, on value steps with key
+    # steps at the pairs' ends
+    exp = O.align_batch(*batch, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=16)
+    assert all((a == b).all() for a, b in zip(got, exp))
     # checksum of checksums for the record (recomputable from the seeds)
     assert int(got[0].sum()) > 0 and (got[1] < batch[4]).all() and (got[2] < batch[5] + 8).all()
 

@@ -108,6 +108,57 @@ def test_strong_scaling_path_two_process_gloo():
         assert dict(ret) == {0: True, 1: True}
 
 
+def _chunk_worker(rank, world, port, ret):
+    """bench.py --scaling strong on a shape with a chunked generator: every rank draws all the lengths, deals the CHUNKS of 64
+    consecutive pairs by LPT, generates ONLY its own chunks (a random stream per chunk), aligns them (the oracle stands in for the
+    GPU) and the one all-gather restores input order; compared with the whole batch generated and aligned in one piece."""
+    import torch
+    import torch.distributed as dist
+    from agatha_amd import workload
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, seed, gen = 300, 41, "cfg_c0"
+    lens = workload.chunked_lengths(gen, n, seed)
+    nch = (n + workload.CHUNK - 1) // workload.CHUNK
+    cost = np.add.reduceat(shard.nominal_cells(lens, lens, 100), np.arange(0, n, workload.CHUNK))
+    parts = shard.lpt_partition(cost, world)
+    qb, tb, qo, to, ql, tl, ids = workload.chunked_pairs(gen, seed, lens, parts[rank])
+    P = O.make_params(w=100, z=100)
+    local = torch.from_numpy(np.stack(O.align_batch(qb, tb, qo, to, ql, tl, P, wide=True)).astype(np.int32))
+    full = shard.gather_results_tensor(local, torch.from_numpy(ids), n, dist, torch).numpy()
+    whole = workload.chunked_pairs(gen, seed, lens, range(nch))
+    exp = np.stack(O.align_batch(*whole[:6], P, wide=True))
+    own = sorted(int(c) for c in parts[rank])
+    ret[rank] = bool((full == exp).all()) and bool((whole[6] == np.arange(n)).all()) and len(ids) == sum(min(n, (c + 1) * 64) - c * 64 for c in own)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_with_per_rank_chunks_two_process_gloo():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_chunk_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}
+
+
+def test_chunked_generator_is_the_same_whatever_the_shard():
+    """A chunk's pairs do not depend on which other chunks are generated with it, the lengths follow the shape's law, reads are the
+    references through the shape's error channel (lengths within a few per cent), the wire format is the GASAL host batch."""
+    from agatha_amd import workload
+    lens = workload.chunked_lengths("cfg_c1", 1000, 7)
+    assert lens.min() >= 8000 and lens.max() <= 12000 and abs(lens.mean() - 10000) < 200
+    a = workload.chunked_pairs("cfg_c1", 7, lens, [5])
+    b = workload.chunked_pairs("cfg_c1", 7, lens, [2, 5, 9])
+    k = 64
+    assert (a[4] == b[4][k:2 * k]).all() and (a[5] == b[5][k:2 * k]).all() and (a[6] == b[6][k:2 * k]).all()
+    assert bytes(a[0]) == bytes(b[0][b[2][k]:b[2][2 * k]]) and bytes(a[1]) == bytes(b[1][b[3][k]:b[3][2 * k]])
+    assert (a[2] % 8 == 0).all() and (a[4] == lens[320:384]).all()
+    assert np.abs(a[5].astype(np.int64) - a[4]).max() < 0.05 * a[4].max()
+    assert set(np.unique(a[0]).tolist()) <= set(b"ACGTN")
+
+
 def test_fasta_index_reads_only_byte_ranges(tmp_path):
     """agatha_amd.multi_gpu: the vectorised FASTA index (offsets, op codes, lengths without decoding a sequence) and the
     per-record reads agree with the plain sequential reader, for ragged line widths, CRLF, empty lines and every op code."""
