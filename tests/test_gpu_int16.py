@@ -257,12 +257,20 @@ def test_n_runs_in_the_query_on_the_int16_kernel(eng, p):
     assert _same(got, exp)
     assert kinds[1] == 0 and kinds[2] == 0
     assert st[0] > 0 and st[1] > 0                  # value steps, and key steps where N rows were in flight
-    agatha_amd.set_debug_option("force_choice", 1)            # the latency shape
+    # the latency shape of the window (64 lanes per pair; one pair on two waves at band 1500, where a pair that holds an N stays on
+    # key steps: whether an N row is in flight differs between the two waves, and they must run the same kind of step)
+    agatha_amd.set_debug_option("force_int16", 0)
+    agatha_amd.set_debug_option("force_choice", 1)
     try:
-        got, exp, st, kinds = _run_stats(eng, qs, ts, p)
+        got, exp, st, kinds = _run_stats(eng, qs, ts, p, fast_margin=16)
         assert _same(got, exp) and kinds[2] == 0
+        if p["w"] == 1500:
+            assert _run_stats.choice == ("int16", 128, 2)
+        elif p["w"] >= 500:
+            assert _run_stats.choice == ("int16", 64, 2)
     finally:
         agatha_amd.set_debug_option("force_choice", -1)
+        agatha_amd.set_debug_option("force_int16", 1)
 
 
 @pytest.mark.parametrize("n", [4100, 5000, 8000, 8185, 8192, 8200, 9000, 12288, 12300, 15000, 16384, 16400])
@@ -469,6 +477,7 @@ def _run_stats(eng, qs, ts, p, **opts):
             b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
             got = [b.res_host[j].copy() for j in range(3)]
             st, kinds = b.step_stats(), b.pair_kinds()
+            _run_stats.choice = b.kernel_choice()
         finally:
             b.free()
     return got, exp, st, kinds
@@ -517,16 +526,19 @@ def test_checkpoints_and_going_back_to_them(eng, shape):
     (ck_min_steps = 32: a checkpoint every 256 steps), on the throughput shape and on the latency shape."""
     qs, ts = _broken_batch(71, 240, 6000, 12000, broken=0.5, noisy=0.1)
     p = dict(BASE, z=120)
+    agatha_amd.set_debug_option("force_int16", 0)
     agatha_amd.set_debug_option("force_choice", shape)
     try:
         got, exp, st, kinds = _run_stats(eng, qs, ts, p, ck_min_steps=32)
         assert _same(got, exp)
+        assert _run_stats.choice == ("int16", 64, 2) if shape else _run_stats.choice[:2] == ("int16", 16)
         assert st[15] > 20                # pairs went back to a checkpoint
         assert kinds[2] == 0
         got, exp, st, _ = _run_stats(eng, qs, ts, p, ck_min_steps=0)
         assert _same(got, exp) and st[15] == 0 and st[2] > 20
     finally:
         agatha_amd.set_debug_option("force_choice", -1)
+        agatha_amd.set_debug_option("force_int16", 1)
 
 
 def test_two_wave_shape_moves_the_base_under_a_barrier(eng):
@@ -556,6 +568,34 @@ def test_two_wave_shape_moves_the_base_under_a_barrier(eng):
                 assert b.step_stats()[2] == 0 and b.step_stats()[15] == 0       # nothing had to be started over
         finally:
             b.free()
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
+        agatha_amd.set_debug_option("force_int16", 1)
+
+
+def test_two_wave_shape_with_value_steps_n_rows_and_pairs_started_over(eng):
+    """One pair on two waves (<128, 1>), steep gap scores (the in-band zone is lifted), a small z (pairs are started over all the
+    time), very short and longer pairs, N runs in some queries: the two waves of a pair must always run the same kind of step --
+    the round-3 fuzzer found the case where they did not (an N row in flight is a property of ONE wave's lanes), a hang."""
+    rng = np.random.default_rng(29)
+    qs, ts = [], []
+    for k in range(60):
+        ref = WL.random_seq(rng, int(rng.choice([5, 40, 300, 835, 2000, 3900])))
+        rd = WL.mutate(rng, ref, 0.05, 0.04, 0.04).copy() if k % 3 else WL.random_seq(rng, int(rng.integers(1, 3000)))
+        if rd.size == 0:
+            rd = WL.random_seq(rng, 1)
+        ref = ref.copy()
+        if k % 4 == 1 and ref.size > 30:
+            a = int(rng.integers(0, ref.size - 20)); ref[a:a + int(rng.integers(1, 20))] = ord("N")
+        qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    agatha_amd.set_debug_option("force_int16", 0)
+    agatha_amd.set_debug_option("force_choice", 1)
+    try:
+        for p in (dict(m=2, x=6, q=20, r=2, s=1, z=50, w=1500), dict(m=2, x=6, q=20, r=2, s=3, z=-1, w=1500), dict(BASE, w=1500, z=30)):
+            for margin in (16, 3):
+                got, exp, st, kinds = _run_stats(eng, qs, ts, p, fast_margin=margin, ck_min_steps=16)
+                assert _run_stats.choice == ("int16", 128, 2)
+                assert _same(got, exp), (p, margin)
     finally:
         agatha_amd.set_debug_option("force_choice", -1)
         agatha_amd.set_debug_option("force_int16", 1)

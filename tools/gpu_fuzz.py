@@ -46,18 +46,34 @@ while time.time() < t_end:
             ref = ref.copy(); ref[rng.random(ref.size) < 0.03] = ord("N")
         qs.append(ref.tobytes()); ts.append(rd.tobytes())
     qb, qo, ql = WL.make_batch(qs); tb, to, tl = WL.make_batch(ts)
+    if os.environ.get("FUZZ_ONLY") and trials != int(os.environ["FUZZ_ONLY"]):
+        vs = dict(fast_margin=int(rng.choice([0, 1, 3, 8, 16, 64])), ck_min_steps=int(rng.choice([0, 16, 256, 4096])))
+        [rng.integers(0, 2) for _ in range(3)]
+        trials += 1
+        continue
     exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=16)
     # (value steps of the int16 kernel: the window of key steps at a pair's end and the checkpoints vary as well)
     vs = dict(fast_margin=int(rng.choice([0, 1, 3, 8, 16, 64])), ck_min_steps=int(rng.choice([0, 16, 256, 4096])))
+    for k_, v_ in os.environ.items():          # (tools/fuzz_one.py: override an option / a parameter of the trial)
+        if k_.startswith("FUZZ_FORCE_"): vs[k_[11:].lower()] = int(v_)
+        if k_.startswith("FUZZ_PARAM_"): p[k_[11:].lower()] = int(v_)
+    if any(k_.startswith("FUZZ_PARAM_") for k_ in os.environ):
+        exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=16)
     for mode, opts in (("choice", dict(vs)), ("int16", dict(vs, force_int16=1)), ("int32", {"no_int16": 1})):
+        if os.environ.get("FUZZ_VERBOSE"): print("trial", trials, mode, p, vs, "n", len(ql), "lmax", lmax, flush=True)
         with agatha_amd.debug_options(**opts):
-            got = eng.align_host_batch(qb, tb, qo, to, ql, tl, agatha_amd.Scores.make(**p), use_len_hint=bool(rng.integers(0, 2)))
+            hint = bool(rng.integers(0, 2))
+            got = eng.align_host_batch(qb, tb, qo, to, ql, tl, agatha_amd.Scores.make(**p), use_len_hint=hint)
         diff = [i for i in range(len(ql)) if any(int(exp[j][i]) != int(got[j][i]) for j in range(3))]
         if diff:
             bad += 1
             i = diff[0]
             print("MISMATCH", mode, p, "n", len(ql), "pairs", diff[:6], "first: Q", int(ql[i]), "R", int(tl[i]),
                   "exp", [int(exp[j][i]) for j in range(3)], "got", [int(got[j][i]) for j in range(3)], "int16cfg", eng.last_int16_config(), flush=True)
+            if os.environ.get("FUZZ_VERBOSE"):
+                with agatha_amd.debug_options(**opts):
+                    b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p), use_len_hint=hint); b.download(); eng.synchronize()
+                    print("   hint", hint, "choice", b.kernel_choice(), "again:", [int(b.res_host[j][i]) for j in range(3)], "step_stats", b.step_stats(), flush=True); b.free()
     if trials % 3 == 0:
         # the traceback pass on the same batch: scores, ends and every path byte against the oracle's walk
         es, eq, et, ecig, en = O.traceback_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), threads=16)
