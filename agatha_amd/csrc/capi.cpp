@@ -322,6 +322,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.ck_buf = have_ck ? (uint32_t*)((char*)d_workspace + ck_off) : nullptr;
     L.ck_slots = 1 << 30;           // (the area is sized for every lane group any shape's grid can have for this many pairs)
     L.ck_min_steps = opt(OPT_CK_MIN_STEPS);
+    { static std::atomic<int> launches{1}; L.launch_id = launches.fetch_add(1, std::memory_order_relaxed); }
     L.max_blocks_override = opt(OPT_MAX_BLOCKS);
     L.no_deal = opt(OPT_NO_DEAL) ? 1 : 0;
     // Candidates for the plain pairs: the packed-int16 kernel when the scores and the band allow it, the int32 kernel
