@@ -23,9 +23,10 @@ for c in ("C3", "C4"):
     d = {"kernel": name.split("(")[0].replace("void ", ""), "avg_ms": avg_ms, "calls": int(dom["Calls"]), "pmc_mean_per_launch": m,
          "line": open(os.path.join(src, f"prof_{tag}_{c}_trace.txt")).read().strip().splitlines()[-1][:300]}
     if "SQ_INSTS_VALU" in m and "SQ_WAVE_CYCLES" in m:
-        d["valu_issue_share_of_wave_cycles"] = m["SQ_INSTS_VALU"] * 4 / m["SQ_WAVE_CYCLES"] if m["SQ_WAVE_CYCLES"] else None
+        # (SQ_WAVE_CYCLES counts in units of 4 cycles, as one wave64 VALU instruction takes: the ratio is the share of a wave's life in which it issues VALU)
+        d["valu_issue_share_of_wave_cycles"] = m["SQ_INSTS_VALU"] / m["SQ_WAVE_CYCLES"] if m["SQ_WAVE_CYCLES"] else None
     if "SQ_WAIT_INST_ANY" in m and "SQ_WAVE_CYCLES" in m:
-        d["wait_share_of_wave_cycles"] = m["SQ_WAIT_INST_ANY"] * 4 / m["SQ_WAVE_CYCLES"] if m["SQ_WAVE_CYCLES"] else None
+        d["wait_share_of_wave_cycles"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"] if m["SQ_WAVE_CYCLES"] else None
     res[c] = d
     print(c, d["kernel"], "avg ms", round(avg_ms, 2), {k: "%.3g" % v for k, v in m.items()})
 json.dump(res, open(os.path.join(out, "latency_regimes.json"), "w"), indent=1)
