@@ -5,7 +5,7 @@ G=${1:-16}; P=${2:-3}; T0=${3:--1}
 cd "$(dirname "$0")/../agatha_amd/csrc"
 mkdir -p /tmp/isa16
 FLAGS=$(grep '^CXXFLAGS' Makefile | sed 's/CXXFLAGS *= *//; s/\$(ARCH)/gfx950/')
-hipcc $FLAGS -DAGATHA16_NT0=$((-T0)) -DAGATHA16_ONLY_G=$G -DAGATHA16_ONLY_P=$P -S --cuda-device-only -o /tmp/isa16/one.s align16_inst.hip -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|VGPRs:|SGPRs:|Spill|Occupancy|Scratch"
+hipcc $FLAGS -O3 -DAGATHA16_NT0=$((-T0)) -DAGATHA16_ONLY_G=$G -DAGATHA16_ONLY_P=$P -S --cuda-device-only -o /tmp/isa16/one.s align16_inst.hip -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|VGPRs:|SGPRs:|Spill|Occupancy|Scratch"
 python3 - <<'PY'
 import re, collections
 out, skip = [], False
