@@ -18,6 +18,15 @@ hipError_t align16_entry_5(const AlignLaunch&, int, int, int, hipStream_t);
 hipError_t align16_entry_6(const AlignLaunch&, int, int, int, hipStream_t);
 hipError_t align16_entry_7(const AlignLaunch&, int, int, int, hipStream_t);
 
+hipError_t align16_tb_entry_0(const AlignLaunch&, int, int, int, hipStream_t);
+hipError_t align16_tb_entry_1(const AlignLaunch&, int, int, int, hipStream_t);
+hipError_t align16_tb_entry_2(const AlignLaunch&, int, int, int, hipStream_t);
+hipError_t align16_tb_entry_3(const AlignLaunch&, int, int, int, hipStream_t);
+hipError_t align16_tb_entry_4(const AlignLaunch&, int, int, int, hipStream_t);
+hipError_t align16_tb_entry_5(const AlignLaunch&, int, int, int, hipStream_t);
+hipError_t align16_tb_entry_6(const AlignLaunch&, int, int, int, hipStream_t);
+hipError_t align16_tb_entry_7(const AlignLaunch&, int, int, int, hipStream_t);
+
 struct Cfg16 { int G, P; };
 static const Cfg16 kCfgs16[] = {       // ascending G * 2P: windows of 32, 64, 96, 128, 192 blocks; then the latency shapes
     {16, 1}, {16, 2}, {16, 3}, {32, 2}, {32, 3}, {64, 1}, {64, 2}, {128, 1},
@@ -64,6 +73,26 @@ hipError_t launch_align16(const AlignLaunch& L, int G, int P, int kid, hipStream
                                         align16_entry_4, align16_entry_5, align16_entry_6, align16_entry_7};
     const int W = (L.p.band_width + 7) / 8, t0 = L.p.band_width - 8 * W;       // the cut diagonal of edge blocks, 0..-7
     return entries[-t0](L, G, P, kid, st);
+}
+
+// Traceback pass: the int16 shape whose G * 2P equals the slot count of the int32 traceback kernel for this window (both write
+// the code area of a pass, one layout), if the scores allow the kernel at all.
+bool align16_tb_config(const AlignParams& p, int window_blocks, int group_slots, int* G, int* P)
+{
+    if (!agatha16_scores_ok(p)) return false;
+    for (const Cfg16& c : kCfgs16)
+        if (c.P == 3 && c.G * 2 * c.P == group_slots && group_slots >= window_blocks) { *G = c.G; *P = c.P; return true; }
+    return false;
+}
+
+hipError_t launch_align16_tb(const AlignLaunch& L, int G, int P, int pass, hipStream_t st)
+{
+    typedef hipError_t (*entry_fn)(const AlignLaunch&, int, int, int, hipStream_t);
+    static const entry_fn entries[8] = {align16_tb_entry_0, align16_tb_entry_1, align16_tb_entry_2, align16_tb_entry_3,
+                                        align16_tb_entry_4, align16_tb_entry_5, align16_tb_entry_6, align16_tb_entry_7};
+    if (!L.tb_codes || !L.tb_off || !L.tb_pass || !L.tb_plan) return hipErrorInvalidValue;
+    const int W = (L.p.band_width + 7) / 8, t0 = L.p.band_width - 8 * W;
+    return entries[-t0](L, G, P, pass, st);
 }
 
 }  // namespace agatha

@@ -157,6 +157,7 @@ backtrace_kernel(AlignLaunch L, int GS, int pass, uint8_t* __restrict__ cigar, u
 
     int cq = -1, cr = -1;                      // block whose code words the lanes hold (all zero: the pass never computed it)
     uint32_t myw = 0u;                         // lane l < 8: code word of row l of that block
+    bool cedge = false;                        // ... is a boundary block of the band (agatha_kernel.h:243): the band is tested per cell
     int wqi = -1, wti = -1;
     uint32_t wq = 0u, wt = 0u;
     // code of cell (i, j), 0 if the scoring pass never computed it
@@ -171,7 +172,11 @@ backtrace_kernel(AlignLaunch L, int GS, int pass, uint8_t* __restrict__ cigar, u
             const int se = imin(imin(prl - 1, i0 + sw - 1), (((i0 + sw - 1) * 8 + 7 + w) / 2) / 8);
             if (r >= prl || q < cs || q > ce || r < ss || r > se) myw = 0u;
             else myw = tb[((size_t)step * GS + (size_t)(r % GS)) * 8 + (size_t)(lane & 7)];
+            cedge = (q == cs) || (q == ce);
         }
+        // (the int32 kernel leaves 0 in the cells of a boundary block that lie outside the band; the int16 kernel computes -- and
+        //  codes -- every cell of a block it computes, so the band is looked at here)
+        if (cedge && (j - i > w || i - j > w)) return 0u;
         const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)myw, i & 7);
         return (word >> (4 * (j & 7))) & 15u;
     };

@@ -343,8 +343,14 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.self_dev = rec;
     HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record, queue head reset, kernel choice; stream-ordered
     if (tb) {
+        // the pairs with plain letters run on the int16 kernel where a shape with the pass's slot count exists (bands of 49..192
+        // blocks), the int32 kernel behind it takes the rest of the pass: other letters, N in the query, pairs it abandoned
+        int G16 = 0, P16 = 0;
+        const bool tb16 = opt(OPT_NO_INT16) == 0 && agatha::align16_tb_config(L.p, (int)window, tb_gs, &G16, &P16);
+        g_last16 = tb16 ? ((G16 << 8) | (2 * P16)) : 0;
         for (int pass = 0; pass < tb_passes; pass++) {
             if (pass > 0) HIPCHK(agatha::launch_record(L, rec, st));       // queue heads back to 0
+            if (tb16) HIPCHK(agatha::launch_align16_tb(L, G16, P16, pass, st));
             HIPCHK(agatha::launch_align_tb(L, (int)window, pass, st));
             HIPCHK(agatha::launch_backtrace(L, tb_gs, pass, tb->cigar, tb->n_ops, st));
         }

@@ -94,6 +94,11 @@ int max_window_blocks();
 // fewer blocks per lane, of its latency shape (64 lanes per pair; *GL = 0 if none); and its launcher
 bool align16_config(const AlignParams& p, int window_blocks, int* G, int* P, int* GL, int* PL);
 hipError_t launch_align16(const AlignLaunch& L, int G, int P, int kid, hipStream_t st);
+// Traceback pass on the int16 kernel: align16_tb_config says whether a shape with exactly `group_slots` slots exists for these
+// scores (the code layout of a pass is shared with the int32 traceback kernel); launch_align16_tb runs the pairs of `pass`
+// that have plain letters and no N in the query, and marks the ones it finished (kind 4 in L.exotic).
+bool align16_tb_config(const AlignParams& p, int window_blocks, int group_slots, int* G, int* P);
+hipError_t launch_align16_tb(const AlignLaunch& L, int G, int P, int pass, hipStream_t st);
 int key_bits_for_window(int window_blocks);
 // writes L into *rec on the device (by-value kernel argument: no host-memory lifetime to care about) and zeroes *L.queue
 hipError_t launch_exotic(const AlignLaunch& L, hipStream_t st);
