@@ -155,29 +155,46 @@ backtrace_kernel(AlignLaunch L, int GS, int pass, uint8_t* __restrict__ cigar, u
     const int w = L.p.band_width, sw = L.p.slice_width, W = (w + 7) >> 3;
     const int pql = (Q + 7) >> 3, prl = (R + 7) >> 3;
 
-    int cq = -1, cr = -1;                      // block whose code words the lanes hold (all zero: the pass never computed it)
-    uint32_t myw = 0u;                         // lane l < 8: code word of row l of that block
-    bool cedge = false;                        // ... is a boundary block of the band (agatha_kernel.h:243): the band is tested per cell
+    // Lanes 0..7 hold the eight code words of the block the path is in; lanes 8..31 those of the three blocks it can go to from there
+    // -- above, left, above-left --, requested when the path ENTERS a block: the load of the next block is then under way while
+    // this one is walked (the walk is a chain of dependent loads otherwise: measured 16 ms for 6 000 pairs of 10 kb, 4 us per
+    // block).  A block the pass never computed is all zero.
+    int cq = -1, cr = -1;
+    uint32_t cur = 0u, nxt = 0u;               // lane l < 8: word of row l of the current block; lane 8 g + l, g = 1..3: of neighbour g
+    bool cedge = false;                        // the current block is a boundary block of the band (agatha_kernel.h:243): the band is tested per cell
+    const int lg = lane >> 3, ll = lane & 7;
+    const int ldq = (lg == 1 || lg == 3) ? 1 : 0, ldr = (lg == 2 || lg == 3) ? 1 : 0;
+    // (per lane) word ll of block (q, r), 0 if the scoring pass never computed the block
+    auto block_word = [&](int q, int r) -> uint32_t {
+        if (q < 0 || r < 0 || q >= pql || r >= prl) return 0u;
+        const int step = q + r;
+        const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
+        const int i0 = (step / sw) * sw;                              // first step of the slice (agatha_kernel.h:183-187)
+        const int ss = imax(imax(0, i0 - pql + 1), ((i0 * 8 + 8 - w) / 2) / 8);
+        const int se = imin(imin(prl - 1, i0 + sw - 1), (((i0 + sw - 1) * 8 + 7 + w) / 2) / 8);
+        if (q < cs || q > ce || r < ss || r > se) return 0u;
+        if (L.tb_lanes == 0) return tb[((size_t)step * GS + (size_t)(r % GS)) * 8 + (size_t)ll];
+        const int slot = r % GS, s16 = GS / L.tb_lanes, k16 = slot / s16, rem = slot % s16;
+        return tb[(size_t)step * GS * 8 + (size_t)(((((rem >> 1) * 4 + (rem & 1) * 2 + (ll >> 2)) * L.tb_lanes + k16) * 4) + (ll & 3))];
+    };
     int wqi = -1, wti = -1;
     uint32_t wq = 0u, wt = 0u;
     // code of cell (i, j), 0 if the scoring pass never computed it
     auto code_of = [&](int i, int j) -> uint32_t {
         const int q = i >> 3, r = j >> 3;
         if (q != cq || r != cr) {
+            int hit = 0;
+            if (cq >= 0) hit = (q == cq - 1 && r == cr) ? 1 : (q == cq && r == cr - 1) ? 2 : (q == cq - 1 && r == cr - 1) ? 3 : 0;
             cq = q; cr = r;
-            const int step = q + r;
-            const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
-            const int i0 = (step / sw) * sw;                              // first step of the slice (agatha_kernel.h:183-187)
-            const int ss = imax(imax(0, i0 - pql + 1), ((i0 * 8 + 8 - w) / 2) / 8);
-            const int se = imin(imin(prl - 1, i0 + sw - 1), (((i0 + sw - 1) * 8 + 7 + w) / 2) / 8);
-            if (r >= prl || q < cs || q > ce || r < ss || r > se) myw = 0u;
-            else myw = tb[((size_t)step * GS + (size_t)(r % GS)) * 8 + (size_t)(lane & 7)];
-            cedge = (q == cs) || (q == ce);
+            if (hit) cur = (uint32_t)__shfl((int)nxt, ll + 8 * hit);
+            else cur = (lane < 8) ? block_word(q, r) : 0u;
+            nxt = (lane >= 8 && lane < 32) ? block_word(q - ldq, r - ldr) : 0u;
+            cedge = (q == imax(0, r - W)) || (q == imin(pql - 1, r + W));
         }
         // (the int32 kernel leaves 0 in the cells of a boundary block that lie outside the band; the int16 kernel computes -- and
         //  codes -- every cell of a block it computes, so the band is looked at here)
         if (cedge && (j - i > w || i - j > w)) return 0u;
-        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)myw, i & 7);
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur, i & 7);
         return (word >> (4 * (j & 7))) & 15u;
     };
     auto diag_op = [&](int i, int j) -> uint32_t {

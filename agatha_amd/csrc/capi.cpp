@@ -281,9 +281,10 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.step_stats = queue + 20;
     L.score_limit = score_limit;
     L.force_cmp = (tb || sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
-    L.tb_codes = nullptr; L.tb_off = nullptr; L.tb_pass = nullptr; L.tb_plan = nullptr;
+    L.tb_codes = nullptr; L.tb_off = nullptr; L.tb_pass = nullptr; L.tb_plan = nullptr; L.tb_lanes = 0;
     HIPCHK(agatha::launch_exotic(L, st));
-    int tb_passes = 0, tb_gs = 0;
+    int tb_passes = 0, tb_gs = 0, G16 = 0, P16 = 0;
+    bool tb16 = false;
     if (tb) {
         // scratch = [word offset of every pair's codes | its pass | the plan | the code area]; the number of passes launched
         // is the worst case (every pair as long as the hints): a pass the plan did not need returns at once, so that the
@@ -303,6 +304,8 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         int* pass = (int*)p;                                 p += round_up(4 * (size_t)n_alns);
         int* plan = (int*)p;                                 p += kAlign;
         L.tb_codes = (uint32_t*)p; L.tb_off = off; L.tb_pass = pass; L.tb_plan = plan;
+        tb16 = opt(OPT_NO_INT16) == 0 && agatha::align16_tb_config(L.p, (int)window, tb_gs, &G16, &P16);
+        L.tb_lanes = tb16 ? G16 : 0;           // (the layout of the code words: both kernels of a pass and the walk read it)
         HIPCHK(agatha::launch_tb_plan(L, tb_gs, (unsigned long long)(cap / 4), tb_passes, off, pass, plan, st));
     }
     L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;
@@ -345,8 +348,6 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     if (tb) {
         // the pairs with plain letters run on the int16 kernel where a shape with the pass's slot count exists (bands of 49..192
         // blocks), the int32 kernel behind it takes the rest of the pass: other letters, N in the query, pairs it abandoned
-        int G16 = 0, P16 = 0;
-        const bool tb16 = opt(OPT_NO_INT16) == 0 && agatha::align16_tb_config(L.p, (int)window, tb_gs, &G16, &P16);
         g_last16 = tb16 ? ((G16 << 8) | (2 * P16)) : 0;
         for (int pass = 0; pass < tb_passes; pass++) {
             if (pass > 0) HIPCHK(agatha::launch_record(L, rec, st));       // queue heads back to 0

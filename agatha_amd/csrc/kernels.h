@@ -65,6 +65,9 @@ struct AlignLaunch {
     const int* tb_pass;            // device: the pass a pair belongs to (the code area is reused pass after pass); -1 = its codes
                                    // do not fit the area at all (AGATHA_AMD_BAD_RESULT)
     const int* tb_plan;            // device: [0] number of passes
+    // layout of a step's G*S*8 code words: 0 = block-major (slot, row); L > 0 = the int16 kernel's, lane-major for its L lanes per
+    // pair: [register pair][half][rows 0-3 | 4-7][lane][4 words], so that one store instruction of a lane group is contiguous
+    int tb_lanes;
 };
 
 // states of a boundary (the pair whose steps are split between lane groups b - 1 and b)

@@ -74,7 +74,7 @@ while time.time() < t_end:
                 with agatha_amd.debug_options(**opts):
                     b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p), use_len_hint=hint); b.download(); eng.synchronize()
                     print("   hint", hint, "choice", b.kernel_choice(), "again:", [int(b.res_host[j][i]) for j in range(3)], "step_stats", b.step_stats(), flush=True); b.free()
-    if trials % 3 == 0:
+    if trials % int(os.environ.get("FUZZ_TB_EVERY", "3")) == 0:
         # the traceback pass on the same batch: scores, ends and every path byte against the oracle's walk
         es, eq, et, ecig, en = O.traceback_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), threads=16)
         b = eng.batch(qb, tb, qo, to, ql, tl)
