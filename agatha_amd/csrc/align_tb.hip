@@ -224,7 +224,36 @@ backtrace_kernel(AlignLaunch L, int GS, int pass, uint8_t* __restrict__ cigar, u
         if (code == 0u) { bad = true; break; }
         if (state == 0) {
             const uint32_t d = code & 3u;
-            if (d == 1u) { emit(diag_op(i, j)); i--; j--; }
+            if (d == 1u) {
+                // Most of a path is diagonal moves, and the scalar unit -- one per CU, one instruction per cycle for all of its
+                // waves -- is what the walk runs on: the diagonal from (i, j) to the edge of the block is looked at by the lanes
+                // at once (lane l: the cell of row l on it), two ballots say how far the path follows it and where bases match,
+                // and the scalar program only sees the ends of the runs.
+                const int il = i & 7, jl = j & 7, m = il < jl ? il : jl;
+                if (cq != wqi) { wqi = cq; wq = uniu(pq[wqi]); }
+                if (cr != wti) { wti = cr; wt = uniu(pt[wti]); }
+                const int t = il - lane, c = jl - t;                                  // (per lane) steps back along the diagonal, column in the block
+                const bool valid = t >= 0 && t <= m;
+                uint32_t nibv = valid ? ((cur >> (4 * (c & 7))) & 15u) : 0u;
+                if (cedge) { const int row = 8 * cq + lane, col = 8 * cr + c; if (col - row > w || row - col > w) nibv = 0u; }
+                const uint32_t av = (wq >> (28 - 4 * (lane & 7))) & 15u, bv = (wt >> (28 - 4 * (c & 7))) & 15u;
+                const uint32_t dm = (uint32_t)__builtin_amdgcn_ballot_w64(valid && (nibv & 3u) == 1u);
+                const uint32_t mm = (uint32_t)__builtin_amdgcn_ballot_w64(valid && av == bv && av != N_VALUE);
+                const uint32_t stop = ~dm & ((2u << il) - 1u);                       // lanes at or below il whose cell leaves the diagonal (or is none)
+                const int n = stop ? il - (31 - __builtin_clz(stop)) : il + 1;       // >= 1: the cell (i, j) itself is on it
+                const int pend = il - n;
+                const uint32_t lowm = pend >= 0 ? ((2u << pend) - 1u) : 0u;
+                for (int p = il; p > pend;) {
+                    const uint32_t bit = (mm >> p) & 1u;
+                    const uint32_t z = (bit ? ~mm : mm) & ((2u << p) - 1u) & ~lowm;   // lanes in (pend, p] with the other op
+                    const int k = z ? p - (31 - __builtin_clz(z)) : p - pend;
+                    const uint32_t op = bit ? 0u : 1u;
+                    if (op == run_op) run += (uint32_t)k;
+                    else { if (run) flush(); run_op = op; run = (uint32_t)k; }
+                    p -= k;
+                }
+                i -= n; j -= n; guard -= n - 1;
+            }
             else state = (int)d - 1;
         } else if (state == 1) {
             emit(2u); j--;

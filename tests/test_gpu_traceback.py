@@ -32,7 +32,8 @@ def _pairs(seed, n, lo, hi, sub=0.05, ins=0.04, dele=0.04, n_every=7):
     return qs, ts
 
 
-def _traceback(eng, qs, ts, scratch_bytes=None, **p):
+def _traceback(eng, qs, ts, scratch_bytes=None, stats=False, **p):
+    """stats: also (the int16 kernel's step statistics of the call, the pair kinds it left)"""
     import agatha_amd
     qb, qo, ql = O.make_batch(qs)
     tb, to, tl = O.make_batch(ts)
@@ -40,7 +41,8 @@ def _traceback(eng, qs, ts, scratch_bytes=None, **p):
     try:
         b.upload()
         b.pack()
-        return b.align_traceback(agatha_amd.Scores.make(**p), scratch_bytes=scratch_bytes)
+        got = b.align_traceback(agatha_amd.Scores.make(**p), scratch_bytes=scratch_bytes)
+        return (got, b.step_stats(), eng.last_int16_config()) if stats else got
     finally:
         b.free()
 
@@ -209,3 +211,41 @@ def test_single_pair_and_tiny_batches(eng):
         qs, ts = _pairs(200 + n, n, 1, 50)
         got = _traceback(eng, qs, ts, w=8, z=-1)
         _check(qs, ts, got, w=8, z=-1)
+
+
+@pytest.mark.parametrize("w,z,lo,hi,n,shape", [(751, 400, 2000, 9000, 40, (16, 6)), (400, 400, 1000, 5000, 40, (16, 6)),
+                                                 (1000, -1, 3000, 9000, 12, (32, 6)), (1528, 400, 4000, 9000, 8, (32, 6))])
+def test_the_int16_kernel_records_the_codes(eng, w, z, lo, hi, n, shape):
+    """Bands of 49..192 blocks with scores the packed kernel takes: the pass runs on align16_kernel<.., true> (one pair with an N in
+    its query per seven and whatever it abandons go to the int32 kernel of the same pass, which writes the same layout); every
+    path byte against the oracle, and the same bytes with the int16 kernel switched off."""
+    import agatha_amd
+    qs, ts = _pairs(4000 + w, n, lo, hi)
+    rng = np.random.default_rng(w)
+    for k in range(1, n, 5):                                     # unrelated tails: z-drop (or a long gap) inside the band
+        t = bytearray(ts[k]); h = len(t) * 2 // 3
+        t[h:] = bytes(synth.random_seq(rng, len(t) - h)); ts[k] = bytes(t)
+    got, st, cfg = _traceback(eng, qs, ts, stats=True, w=w, z=z)
+    assert cfg == shape and st[3] >= n - (n + 6) // 7 - 2 and st[0] == 0 and st[1] > 0        # pairs started on key steps only
+    assert _check(qs, ts, got, threads=16, w=w, z=z) > n // 2
+    agatha_amd.set_debug_option("no_int16", 1)
+    try:
+        ref, st32, _ = _traceback(eng, qs, ts, stats=True, w=w, z=z)
+    finally:
+        agatha_amd.set_debug_option("no_int16", 0)
+    assert st32[3] == 0
+    assert all((a == b).all() for a, b in zip(got[:3], ref[:3])) and got[3] == ref[3]
+
+
+def test_int16_codes_in_several_passes(eng):
+    """The scratch holds three pairs of the longest kind: the int16 kernel of every pass takes the pairs of that pass only."""
+    import ctypes as C
+    import agatha_amd
+    qs, ts = _pairs(78, 40, 1500, 4000)
+    p = dict(w=751, z=400)
+    small = eng.lib.agatha_amd_traceback_scratch_bytes(40, max(map(len, qs)), max(map(len, ts)), C.byref(agatha_amd.Scores.make(**p)), 3)
+    whole = _traceback(eng, qs, ts, **p)
+    parts, st, cfg = _traceback(eng, qs, ts, scratch_bytes=small, stats=True, **p)
+    assert cfg == (16, 6) and st[3] >= 30
+    assert all((a == b).all() for a, b in zip(whole[:3], parts[:3])) and whole[3] == parts[3]
+    _check(qs, ts, parts, **p)
