@@ -8,6 +8,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 cfgname = sys.argv[2] if len(sys.argv) > 2 else "cfg_c1"
 eng = agatha_amd.Engine(0)
 qs, ts = getattr(workload, cfgname)(n=n)
+if os.environ.get("N_RUN_FRAC"):                     # (a run of N in that fraction of the DP-row sequences, like bench.py --n-run-frac)
+    qs = workload.add_n_runs(qs, float(os.environ["N_RUN_FRAC"]), seed=7)
 qb, qo, ql = workload.make_batch(qs); tb, to, tl = workload.make_batch(ts)
 b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); eng.synchronize()
 sc = agatha_amd.Scores.make()
