@@ -147,7 +147,10 @@ int agatha_amd_align_starts(void* stream, const uint32_t* d_packed_query, const 
  * far fewer passes than its longest pair suggests.  max_query_len / max_target_len are REQUIRED here (non-zero, true upper bounds):
  * the host launches the number of passes they imply without waiting for the device's plan (passes the plan does not need
  * return at once); should a pair be longer than the hints, the pairs left over get AGATHA_AMD_BAD_RESULT / AGATHA_AMD_NO_PATH,
- * as does a pair whose codes do not fit the area even alone.  d_workspace as for agatha_amd_align. */
+ * as does a pair whose codes do not fit the area even alone.  d_workspace as for agatha_amd_align.
+ * The recording kernel is the packed-int16 one for bands of 49..192 blocks (w = 377..1528) with scores it takes, the int32 one
+ * otherwise and for what the int16 kernel leaves (other letters, N in the query, abandoned pairs): results and bytes do not
+ * depend on which (debug option no_int16; agatha_amd_step_stats() after the call counts the pairs the int16 kernel started). */
 #define AGATHA_AMD_NO_PATH 0xFFFFFFFFu
 size_t agatha_amd_traceback_pair_bytes(uint32_t max_query_len, uint32_t max_target_len, const agatha_amd_scores* scores);
 /* pairs_per_pass: 0 = the whole batch in one pass (for pairs as long as the hints) */
