@@ -210,7 +210,13 @@ int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_a
 /* Diagnostics: what the packed-int16 kernel's steps were in the last agatha_amd_align() on this workspace: out[0] = wave-steps
  * on packed maxima of H alone ("value steps"), out[1] = wave-steps with H : column keys ("key steps": a pair's last steps,
  * pairs that were started over), out[2] = pairs started over on key steps (z-drop came into reach on a value step, or the
- * pair ended without knowing the cell of its maximum), out[3] = pairs started.  Synchronises the stream. */
+ * pair ended without knowing the cell of its maximum) from their first step, out[3] = pairs started, out[15] = pairs taken back to a
+ * checkpoint instead, out[24] = pairs handed to the int32 kernel instead (static schedule without checkpoints: debug option
+ * static_ck = 0); out[4..6] why (a value step that was not calm / a key step that needed the cell / the end of a pair without it);
+ * out[16..23] = how far back the checkpoint lay, in units of 256 steps; out[25..32] = how far the pairs that started from their first
+ * step had come, in units of 512 steps, and out[33..37] why the ones beyond 1024 steps had no checkpoint to go back to (second time
+ * / pair too short for checkpoints / before its second checkpoint / resumed pair: the state it was resumed from is used / slot
+ * overwritten).  Synchronises the stream. */
 int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[40]);
 
 /* Diagnostics (debug option "timeline" = 1, workspace sized for > 4096 pairs): where and when every wave of the packed-int16

@@ -425,7 +425,9 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
             }
         }
         /* ---- value steps: the calm test on values alone, the mode of this step ---- */
-        const int fast = margin > 0 && i < total - margin;
+        /* (the kernel's window of key steps, align16_body.inc `ewin`: from `margin` + 1/128 of the steps before the block anti-diagonal of
+         *  the corner the shorter sequence ends in, to the pair's end) */
+        const int fast = margin > 0 && i < 2 * (pql < prl ? pql : prl) - 1 - margin - ((pql + prl) >> 7);
         int calm = 0, stale = 0;
         if (margin > 0) {
             int32_t lo8 = INT_MIN, mk = INT_MIN;

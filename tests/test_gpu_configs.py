@@ -154,3 +154,52 @@ def test_identity_pairs_score_linearly(eng):
     _, got = _run(eng, seqs, seqs, m=2, x=4, q=4, r=2, s=3, z=400, w=751)
     for s, L, q, t in zip(got[0], map(len, seqs), got[1], got[2]):
         assert (s, q, t) == (2 * L, L - 1, L - 1)
+
+
+def _sampled_check(batch_lists, got, k, p):
+    qs, ts = batch_lists
+    sb = O.make_batch([qs[i] for i in k]), O.make_batch([ts[i] for i in k])
+    exp = O.align_batch(sb[0][0], sb[1][0], sb[0][1], sb[1][1], sb[0][2], sb[1][2], O.make_params(**p), wide=True,
+                        model=O.MODEL_SLICES, threads=16)
+    assert all((np.asarray(a)[k] == b).all() for a, b in zip(got, exp))
+
+
+@pytest.mark.parametrize("cut", ["target", "query"])
+def test_c1_pairs_of_unequal_lengths_on_the_static_schedule(eng, cut):
+    """10 000 C1 pairs with one sequence cut to 85 %: the maximum of such an extension rises for the last time where the SHORTER
+    sequence ends, 190 steps before the pair's last step.  The window of key steps at a pair's end is anchored there (a window
+    anchored at the last step made every one of these pairs start over: 70 ms instead of 27): no pair is started over, taken
+    back or handed to the int32 kernel, and 400 sampled pairs are the oracle's."""
+    qs, ts = synth.cfg_c1(n=10000)
+    if cut == "target":
+        ts = [t[:int(len(t) * 0.85)] for t in ts]
+    else:
+        qs = [q[:int(len(q) * 0.85)] for q in qs]
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
+    batch, got, (choice, sched, st, kinds) = _run_batch(eng, qs, ts, **p)
+    assert choice == ("int16", 16, 6) and sched[0]
+    assert st[2] == 0 and st[15] == 0 and st[24] == 0 and kinds[2] == 0 and st[0] > 4 * st[1]
+    _sampled_check((qs, ts), got, np.sort(np.random.default_rng(8).choice(10000, 400, replace=False)), p)
+
+
+def test_c1_with_broken_pairs_on_the_static_schedule(eng):
+    """2 % of 10 000 C1 reads have an unrelated tail: z-drop ends those extensions, on a value step that cannot decide it.  On the
+    static schedule such a pair goes back to a checkpoint in place (it ends early, so its lane group has the steps to spare); none
+    goes to the int32 kernel behind.  All the broken pairs and 300 others against the oracle."""
+    qs, ts = synth.cfg_c1(n=10000)
+    rng = np.random.default_rng(21)
+    broken = np.sort(rng.choice(10000, 200, replace=False))
+    ts = list(ts)
+    for i in broken:
+        a = np.frombuffer(ts[i], np.uint8).copy()
+        h = int(rng.integers(len(a) // 10, len(a)))
+        a[h:] = synth.random_seq(rng, len(a) - h)
+        ts[i] = a.tobytes()
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
+    batch, got, (choice, sched, st, kinds) = _run_batch(eng, qs, ts, **p)
+    assert choice == ("int16", 16, 6) and sched[0]
+    assert st[15] > 100 and st[24] == 0 and kinds[2] == 0
+    others = np.setdiff1d(np.random.default_rng(9).choice(10000, 300, replace=False), broken)
+    _sampled_check((qs, ts), got, np.sort(np.concatenate([broken, others])), p)
+    ql, tl = batch[4].astype(np.int64), batch[5].astype(np.int64)
+    assert np.mean((got[1] + got[2] + 2 < 0.95 * (ql + tl))[broken]) > 0.7          # they did end early
