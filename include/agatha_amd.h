@@ -216,7 +216,8 @@ int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_a
  * out[16..23] = how far back the checkpoint lay, in units of 256 steps; out[25..32] = how far the pairs that started from their first
  * step had come, in units of 512 steps, and out[33..37] why the ones beyond 1024 steps had no checkpoint to go back to (second time
  * / pair too short for checkpoints / before its second checkpoint / resumed pair: the state it was resumed from is used / slot
- * overwritten).  Synchronises the stream. */
+ * overwritten), out[38] = pairs that were suspended with an older checkpoint instead of their present state.
+ * Synchronises the stream. */
 int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[40]);
 
 /* Diagnostics (debug option "timeline" = 1, workspace sized for > 4096 pairs): where and when every wave of the packed-int16

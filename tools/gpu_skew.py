@@ -31,7 +31,7 @@ for name, fq, ft in (("equal", 1.0, 1.0), ("target 90 %", 1.0, 0.9), ("target 75
     st = b.step_stats()
     cells = W.nominal_cells_total(ql, tl, 751)
     print(f"{name:12s} align {min(ms):7.2f} ms  {cells / min(ms) / 1e6:7.1f} GCUPS  value steps {st[0]} key steps {st[1]} started over {st[2]} back to checkpoint {st[15]} "
-          f"to int32 {st[24]} ended without the cell {st[6]} not calm on values {st[4]} key step without the cell {st[5]} back by n x 256 steps {st[16:24]} started over at n x 512 steps {st[25:33]} why (second time, no checkpoints, c0 < span, c0 <= first, slot invalid) {st[33:38]}")
+          f"to int32 {st[24]} ended without the cell {st[6]} not calm on values {st[4]} key step without the cell {st[5]} back by n x 256 steps {st[16:24]} started over at n x 512 steps {st[25:33]} why (second time, no checkpoints, c0 < span, c0 <= first, slot invalid) {st[33:38]} suspended with an older checkpoint {st[38]}")
     if "--timeline" in sys.argv:
         agatha_amd.set_debug_option("timeline", 1)
         b.align(sc); eng.synchronize()
