@@ -40,10 +40,11 @@ DebugOption g_opts[] = {
     {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts)
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
     {"fast_margin", "AGATHA_AMD_FAST_MARGIN", {12}},   // int16 kernel: value steps except in a window of key steps at a pair's end that starts n + steps / 128 before the corner of the shorter sequence; 0: key steps only
+    {"fast_anchor", "AGATHA_AMD_FAST_ANCHOR", {1}},   // int16 kernel: 1 = the window of key steps is anchored at the corner of the shorter sequence, 0 = at the pair's last step (experiments)
     {"static_ck", "AGATHA_AMD_STATIC_CK", {1}},   // int16 kernel, static schedule, three register pairs per lane: 1 = checkpoints there as well (a pair that must be started over goes back in place), 0 = none (such a pair goes to the int32 kernel behind)
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {1024}},   // int16 kernel: pairs of at least this many steps take checkpoints (0: none do)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FAST_MARGIN, OPT_STATIC_CK, OPT_CK_MIN_STEPS, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -327,6 +328,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.ck_slots = 1 << 30;           // (the area is sized for every lane group any shape's grid can have for this many pairs)
     L.ck_min_steps = opt(OPT_CK_MIN_STEPS);
     L.static_ck = opt(OPT_STATIC_CK) ? 1 : 0;
+    L.fast_anchor = opt(OPT_FAST_ANCHOR) ? 1 : 0;
     { static std::atomic<int> launches{1}; L.launch_id = launches.fetch_add(1, std::memory_order_relaxed); }
     L.max_blocks_override = opt(OPT_MAX_BLOCKS);
     L.no_deal = opt(OPT_NO_DEAL) ? 1 : 0;

@@ -56,6 +56,7 @@ struct AlignLaunch {
     uint32_t* ck_buf;              // device: checkpoints of the int16 kernel's long pairs, two slots of a suspended pair's size per lane group (nullptr: none)
     int ck_slots;                  // lane groups the area has room for
     int ck_min_steps;              // pairs of fewer steps take no checkpoints
+    int fast_anchor;               // 1: the window of key steps starts before the corner of the shorter sequence (default); 0: before the pair's last step (experiments)
     int static_ck;                 // on a static schedule the three-register-pair shapes: 1 = checkpoints and going back to them in place, 0 = none, a pair that must start over goes to the int32 kernel
     int launch_id;                 // a number per agatha_amd_align call (24 bits are stored with every checkpoint: a slot's content must be this call's)
     int fast_margin;               // packed-int16 kernel: > 0 = value steps (align16_body.inc) except in a pair's last fast_margin steps; 0 = key steps only

@@ -1,5 +1,6 @@
 """Developer tool (GPU box): C1-like pairs whose two sequences differ in length (the target is cut to a fraction of the read, or
-the read to a fraction of the target): kernel time and how many pairs the int16 kernel starts over / takes back to a checkpoint.
+the read to a fraction of the target), or a share of whose reads have an unrelated tail: kernel time and how many pairs the int16
+kernel starts over / takes back to a checkpoint (the distances and reasons are counted by -DAGATHA16_DIAG builds only).
 Usage: python3 tools/gpu_skew.py [pairs]"""
 import sys, numpy as np
 sys.path.insert(0, ".")
