@@ -48,6 +48,7 @@ while time.time() < t_end:
     for mode, opts in (("static", dict(mig_timeout_us=500, mig_test_delay_us=int(rng.integers(2000, 30000))) if force_takeover else {}),
                        ("queue", dict(no_migrate=1))):
         vs = dict(fast_margin=int(rng.choice([0, 2, 16, 40])), ck_min_steps=int(rng.choice([0, 16, 4096])))       # value steps, checkpoints
+        vs["static_ck"] = int(rng.integers(0, 2)); vs["fast_anchor"] = int(rng.integers(0, 2))
         with agatha_amd.debug_options(force_int16=1, **vs, **opts):
             b = eng.batch(qb, tb, qo, to, ql, tl)
             try:
