@@ -37,7 +37,7 @@ DebugOption g_opts[] = {
     {"mig_timeout_us", "AGATHA_AMD_MIG_TIMEOUT_US", {50000}},   // wait for a suspended pair this long, then take it over
     {"mig_test_delay_us", "AGATHA_AMD_MIG_TEST_DELAY_US", {0}}, // tests: odd lane groups start this late
     {"prio_slice", "AGATHA_AMD_PRIO_SLICE", {-1}},     // > 0: SIMD partners alternate issue priority every 2^n ticks (10 ns each); -1: 2^15 on a static schedule, off otherwise; 0: off
-    {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts)
+    {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts); -1: also no priority by the length of a wave's pair on the latency shapes' work queue
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
     {"fast_margin", "AGATHA_AMD_FAST_MARGIN", {12}},   // int16 kernel: value steps except in a window of key steps at a pair's end that starts n + steps / 128 before the corner of the shorter sequence; 0: key steps only
     {"fast_anchor", "AGATHA_AMD_FAST_ANCHOR", {1}},   // int16 kernel: 1 = the window of key steps is anchored at the corner of the shorter sequence, 0 = at the pair's last step (experiments)
