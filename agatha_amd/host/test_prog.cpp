@@ -11,10 +11,17 @@
 // the host threads over N GPUs with gasal_set_device (interfaces.cpp:86-116, the call the reference leaves commented
 // out at test_prog.cpp:31).
 // Own reader (each file is parsed on its own, so records with different line counts stay in step).
+// Measurement aids (environment, not flags -- the reference's command line stays as it is): AGATHA_AMD_REPEAT=R runs the pairs of
+// the two files R times over, as if the files were R times as long (a sustained feed without gigabytes of FASTA);
+// AGATHA_AMD_LOOP_STATS=<file> appends "seconds pairs batches threads" of the batch loop (first fill to last result: host fill,
+// H2D, pack, sort, align, D2H, stream-overlapped -- SURVEY.md 8(d)'s wall time; the FASTA parse before it is not in it).
 #include "../../include/gasal_header.h"
 
 #include <math.h>
 #include <omp.h>
+#include <stdlib.h>
+
+#include <chrono>
 
 #include <vector>
 
@@ -71,9 +78,12 @@ int main(int argc, char** argv)
         std::cerr << "Batch1 and target_batch files should be fasta having same number of sequences" << std::endl;
         exit(EXIT_FAILURE);
     }
-    const int total_seqs = (int)Qs.seqs.size();
+    const int file_seqs = (int)Qs.seqs.size();
+    int repeat = 1;
+    if (const char* r = getenv("AGATHA_AMD_REPEAT")) repeat = std::max(1, atoi(r));
+    const int total_seqs = file_seqs * repeat;
     uint32_t max_q = 0, max_t = 0;
-    for (int i = 0; i < total_seqs; i++) {
+    for (int i = 0; i < file_seqs; i++) {
         max_q = std::max<uint32_t>(max_q, (uint32_t)Qs.seqs[i].size());
         max_t = std::max<uint32_t>(max_t, (uint32_t)Ts.seqs[i].size());
     }
@@ -97,7 +107,9 @@ int main(int argc, char** argv)
         gasal_init_streams(&vecs[t], (int)max_q + 7, (int)max_t + 7, (int32_t)maximum_sequence_length, args);
     }
 
-#pragma omp parallel
+    const auto loop_t0 = std::chrono::steady_clock::now();
+    long total_batches = 0;
+#pragma omp parallel reduction(+ : total_batches)
     {
         const int tid = omp_get_thread_num();
         if (n_gpus > 1) gasal_set_device(tid % n_gpus, false);
@@ -116,22 +128,30 @@ int main(int argc, char** argv)
                 int j = 0;
                 const int first = next;
                 for (; seqs_done < n_seqs && j < args->kernel_align_num; j++, seqs_done++, next++) {
+                    const int rec = next % file_seqs;          // (AGATHA_AMD_REPEAT: the files' pairs over again)
                     st->current_n_alns++;
                     if (st->current_n_alns > st->host_max_n_alns) gasal_host_alns_resize(st, st->host_max_n_alns * 2, args);
                     st->host_query_batch_offsets[j] = qidx;
                     st->host_target_batch_offsets[j] = tidx;
                     if (args->isPacked) {       // -k: 4-bit words packed on the host, no pack kernel (ctors.cpp:65-73)
-                        qidx = gasal_host_batch_fill_packed(st, qidx, Qs.seqs[next].c_str(), (uint32_t)Qs.seqs[next].size(), QUERY);
-                        tidx = gasal_host_batch_fill_packed(st, tidx, Ts.seqs[next].c_str(), (uint32_t)Ts.seqs[next].size(), TARGET);
+                        qidx = gasal_host_batch_fill_packed(st, qidx, Qs.seqs[rec].c_str(), (uint32_t)Qs.seqs[rec].size(), QUERY);
+                        tidx = gasal_host_batch_fill_packed(st, tidx, Ts.seqs[rec].c_str(), (uint32_t)Ts.seqs[rec].size(), TARGET);
                     } else {
-                        qidx = gasal_host_batch_fill(st, qidx, Qs.seqs[next].c_str(), (uint32_t)Qs.seqs[next].size(), QUERY);
-                        tidx = gasal_host_batch_fill(st, tidx, Ts.seqs[next].c_str(), (uint32_t)Ts.seqs[next].size(), TARGET);
+                        qidx = gasal_host_batch_fill(st, qidx, Qs.seqs[rec].c_str(), (uint32_t)Qs.seqs[rec].size(), QUERY);
+                        tidx = gasal_host_batch_fill(st, tidx, Ts.seqs[rec].c_str(), (uint32_t)Ts.seqs[rec].size(), TARGET);
                     }
-                    st->host_query_batch_lens[j] = (uint32_t)Qs.seqs[next].size();
-                    st->host_target_batch_lens[j] = (uint32_t)Ts.seqs[next].size();
+                    st->host_query_batch_lens[j] = (uint32_t)Qs.seqs[rec].size();
+                    st->host_target_batch_lens[j] = (uint32_t)Ts.seqs[rec].size();
                 }
-                gasal_op_fill(st, Qs.ops.data() + first, (uint32_t)j, QUERY);
-                gasal_op_fill(st, Ts.ops.data() + first, (uint32_t)j, TARGET);
+                if (repeat == 1) {
+                    gasal_op_fill(st, Qs.ops.data() + first, (uint32_t)j, QUERY);
+                    gasal_op_fill(st, Ts.ops.data() + first, (uint32_t)j, TARGET);
+                } else {                                        // (a batch may wrap around the end of the files)
+                    std::vector<uint8_t> qo_(j), to_(j);
+                    for (int k = 0; k < j; k++) { qo_[k] = Qs.ops[(first + k) % file_seqs]; to_[k] = Ts.ops[(first + k) % file_seqs]; }
+                    gasal_op_fill(st, qo_.data(), (uint32_t)j, QUERY);
+                    gasal_op_fill(st, to_.data(), (uint32_t)j, TARGET);
+                }
                 slot[z].n = j;
                 gasal_aln_async(st, qidx, tidx, (uint32_t)j, args);
                 st->current_n_alns = 0;
@@ -172,6 +192,11 @@ int main(int argc, char** argv)
                 }
             }
         }
+        total_batches += batches_done;
+    }
+    if (const char* path = getenv("AGATHA_AMD_LOOP_STATS")) {
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count();
+        if (FILE* f = fopen(path, "a")) { fprintf(f, "%.6f %d %ld %d\n", sec, total_seqs, total_batches, n_threads); fclose(f); }
     }
 
     for (int t = 0; t < n_threads; t++) {

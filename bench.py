@@ -10,6 +10,11 @@ Workload = BASELINE.json configs[1]: 10 k synthetic ONT-like pairs, ~10 kb, band
 per GPU (weak scaling: every rank aligns its own 10 k pairs; `--scaling strong`: ONE batch, LPT-sharded over the ranks by
 nominal cells, results gathered into input order with one all-gather and verified on rank 0 against a single-GPU run).
 `--config C0..C4` times the other BASELINE workload shapes with the same fields.  Prints ONE JSON line on rank 0.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment (started as plain `python bench.py --gpus 8`): the process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD before it imports torch or touches a GPU and exits
+with the child's code.  At N > 1 the ONE line holds the weak figure (`value`: comparable with N = 1) and a `strong` object: ONE
+batch of BASELINE configs[2] (100 000 HiFi pairs) sharded over the ranks -- the "batch throughput at 8 GPUs" of north_star.
 """
 import argparse
 import json
@@ -105,7 +110,31 @@ def cpu_baseline(qb, tb, qo, to, ql, tl, scoring, w, budget_s=12.0, gpu_res=None
         ok_simd = int(sum(int(all(int(gpu_res[j][i]) == int(r_simd[j][i]) for j in range(3))) for i in range(k)))
         ok_scal = int(sum(int(all(int(gpu_res[j][i]) == int(r_scal[j][i]) for j in range(3))) for i in range(ks)))
         checked = f"GPU results of the last timed step: {ok_simd}/{k} pairs identical to the AVX2 port, {ok_scal}/{ks} to the scalar oracle"
-    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port", "gpu_results_checked": checked,
+    # effective cells: the anti-diagonals up to each pair's z-drop stop, from the same CPU port, over the whole
+    # batch when that takes about half a minute at the rates just measured, else over every k-th pair, scaled
+    effective = None
+    try:
+        from agatha_amd import shard
+        nom_pp = shard.nominal_cells(ql, tl, w).astype(np.float64)
+        scalar_pair = (np.minimum(np.asarray(ql, np.int64), np.asarray(tl, np.int64)) * int(params.match) >= 32000)   # outside the port's int16 domain
+        rate_simd = cells / dt
+        rate_scal = max(O.nominal_cells_np(ql[:ks], tl[:ks], w) / dts, 1.0)
+        est = float(nom_pp[~scalar_pair].sum() / rate_simd + nom_pp[scalar_pair].sum() / rate_scal)
+        stride = max(1, int(np.ceil(est / 30.0)))
+        pick = np.arange(0, n, stride)
+        t0 = time.time()
+        eff, stop, _, nfb = O.effective_cells_batch(qb, tb, np.asarray(qo)[pick], np.asarray(to)[pick], np.asarray(ql)[pick],
+                                                    np.asarray(tl)[pick], params, threads=cores)
+        last_d = np.asarray(ql, np.int64)[pick] + np.asarray(tl, np.int64)[pick] - 2
+        scale = float(nom_pp.sum() / max(nom_pp[pick].sum(), 1.0))
+        effective = {"effective_cells": float(eff.sum()) * scale, "nominal_cells": float(nom_pp.sum()),
+                     "ratio": float(eff.sum() / max(nom_pp[pick].sum(), 1.0)),
+                     "pairs_stopped_early": int((stop < last_d).sum()), "pairs_looked_at": int(len(pick)), "pairs": int(n),
+                     "source": f"oracle/ksw_style_avx2.c (+ scalar exact-band model for {nfb} pairs outside int16), every {stride}. pair, "
+                               f"{time.time() - t0:.1f} s on {cores} cores; cells of the exact band on the cell anti-diagonals 0..stop"}
+    except Exception as e:                  # (the count is an annotation: it must not cost the bench line)
+        effective = {"error": repr(e)}
+    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port", "gpu_results_checked": checked, "effective": effective,
             "sample": f"first {k} pairs of the same batch x{reps} in {dt:.1f} s: anti-diagonal AVX2 int16 kernel "
                       f"(oracle/ksw_style_avx2.c, ksw_extz2-style, exact band), OpenMP schedule(dynamic) over pairs; "
                       f"{r_simd[3]} pairs fell back to scalar (outside int16)",
@@ -115,76 +144,79 @@ def cpu_baseline(qb, tb, qo, to, ql, tl, scoring, w, budget_s=12.0, gpu_res=None
                             "sample": f"first {ks} pairs in {dts:.1f} s, oracle/agatha_oracle.c"}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=0, help="pairs (per GPU when weak scaling); default: the config's own size")
-    ap.add_argument("--config", default="C1", choices=sorted(CONFIGS), help="workload shape of BASELINE.json (default C1 = configs[1], the headline)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank aligns its own batch; strong: ONE batch, LPT-sharded over the ranks, results gathered")
-    ap.add_argument("--n-run-frac", type=float, default=0.0, help="fraction of the DP-row sequences (file 1: reference pieces) that carry a run of N (50-1000 bases)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gasal-api", action="store_true", help="skip the timing of the CLI / GASAL API by the reference's raw.log protocol")
-    a = ap.parse_args()
-    cfg = CONFIGS[a.config]
-    if a.pairs <= 0:
-        a.pairs = cfg["pairs"]
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
 
-    # RCCL / HIP print banners to fd 1 on some boxes (NCCL_DEBUG=VERSION): keep stdout clean for the ONE JSON line
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = "WORLD_SIZE" in os.environ
-    torch = dist = None
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if world != a.gpus and rank == 0:
-        print(f"[bench] note: WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
+def maybe_spawn_ranks(argv, run=None):
+    """`--gpus N` (N > 1) without a launcher around us: start one rank per GPU with torch.distributed.run as a child process and
+    return its exit code; None when this process is a rank itself (or N = 1).  Runs before torch / agatha_amd are imported: a
+    process that has initialised a GPU must not start the ranks, and never re-execs (reference: the only parallel split of the
+    reference is its OpenMP loop over host threads, test_prog.cpp:195-213; one process per GPU replaces it)."""
+    gpus = 1
+    for k, tok in enumerate(argv):
+        if tok == "--gpus" and k + 1 < len(argv):
+            gpus = int(argv[k + 1])
+        elif tok.startswith("--gpus="):
+            gpus = int(tok.split("=", 1)[1])
+    if gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import subprocess
+    worker = os.environ.get("AGATHA_BENCH_WORKER", os.path.abspath(__file__))       # (tests: a stub worker)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), worker, *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cpus() // gpus)))
+    print(f"[bench] --gpus {gpus} without WORLD_SIZE: starting {gpus} ranks as a child process", file=sys.stderr)
+    return (run or subprocess.run)(cmd, env=env).returncode
 
+
+class Ctx:
+    """What every leg of a run shares: the rank, torch / torch.distributed (None when single-process), the engine, the stream."""
+    pass
+
+
+def run_leg(ctx, config, pairs, scaling, steps, warmup, n_run_frac=0.0):
+    """One timed leg: `steps` passes of the hot path over one batch of BASELINE.json config `config` (`pairs` per GPU when weak,
+    in all when strong), bracketed by barrier + synchronize, MAX over ranks.  Returns a dict of what was measured (rank-0 view
+    where it says so) plus the host batch of this rank (for the CPU baseline / the API timing of the caller)."""
     import agatha_amd
-    from agatha_amd import workload
-
-    eng = agatha_amd.Engine(local_rank)
-    stream = None
-    if use_dist:
-        stream = torch.cuda.current_stream().cuda_stream   # run on torch's stream so the gather is ordered behind align
+    from agatha_amd import workload, shard
+    torch, dist, eng, stream = ctx.torch, ctx.dist, ctx.eng, ctx.stream
+    rank, world, use_dist = ctx.rank, ctx.world, ctx.use_dist
+    cfg = CONFIGS[config]
     W_BAND, Z = cfg["w"], cfg["z"]
     scores = agatha_amd.Scores.make(s=3, z=Z, w=W_BAND, **cfg["scoring"])
-    strong = a.scaling == "strong"
+    strong = scaling == "strong"
 
-    # weak scaling: every rank has its own batch (own seed); strong scaling: every rank builds the SAME batch and keeps its
-    # share of the LPT partition by nominal cells (agatha_amd/shard.py) -- no data-path exchange, results gathered at the end
-    from agatha_amd import shard
-    seed = 0xA6A70000 + int(a.config[1]) + (0 if strong else rank)
-    mine = None
-    imbalance = None
-    full = None
+    # weak scaling: every rank has its own batch (own seed); strong scaling: ONE batch, every rank keeps its share of the LPT
+    # partition by nominal cells (agatha_amd/shard.py) -- no data-path exchange, results gathered at the end
+    seed = 0xA6A70000 + int(config[1]) + (0 if strong else rank)
+    mine = imbalance = full = lens = None
+    nch = 0
     chunked = strong and cfg["gen"] in workload._LEN_LAWS
+    if chunked and n_run_frac > 0:
+        raise SystemExit("--n-run-frac is not available with a chunked strong-scaling batch (C0..C3 with --scaling strong)")
     t_gen = time.perf_counter()
     if chunked:
-        # ONE batch of a.pairs pairs, made in chunks of 64 consecutive pairs with a random stream per chunk: every rank draws the
+        # ONE batch of `pairs` pairs, made in chunks of 64 consecutive pairs with a random stream per chunk: every rank draws the
         # lengths of all pairs (one number each), deals the CHUNKS by LPT over their nominal cells, and generates only its own
-        lens = workload.chunked_lengths(cfg["gen"], a.pairs, seed)
+        lens = workload.chunked_lengths(cfg["gen"], pairs, seed)
         _, ins_, del_ = workload._CHANNELS[cfg["gen"]]
         est = shard.nominal_cells(lens, np.rint(lens * (1.0 + ins_ - del_)).astype(np.int64), W_BAND)
-        nch = (a.pairs + workload.CHUNK - 1) // workload.CHUNK
-        chunk_cost = np.add.reduceat(est, np.arange(0, a.pairs, workload.CHUNK))
+        nch = (pairs + workload.CHUNK - 1) // workload.CHUNK
+        chunk_cost = np.add.reduceat(est, np.arange(0, pairs, workload.CHUNK))
         parts = shard.lpt_partition(chunk_cost, world)
         qb, tb, qo, to, ql, tl, mine = workload.chunked_pairs(cfg["gen"], seed, lens, parts[rank])
-        total_batch_pairs = float(a.pairs)
+        total_batch_pairs = float(pairs)
     else:
-        qs, ts = getattr(workload, cfg["gen"])(n=a.pairs, seed=seed)
-        if a.n_run_frac > 0:
-            qs = workload.add_n_runs(qs, a.n_run_frac, seed=7 + rank)
+        qs, ts = getattr(workload, cfg["gen"])(n=pairs, seed=seed)
+        if n_run_frac > 0:
+            qs = workload.add_n_runs(qs, n_run_frac, seed=7 + rank)
         qb, qo, ql = workload.make_batch(qs)
         tb, to, tl = workload.make_batch(ts)
         del qs, ts
@@ -196,7 +228,10 @@ def main():
             total_batch_pairs = float(len(ql))
             qb, tb, qo, to, ql, tl = shard.take_pairs(qb, tb, qo, to, ql, tl, mine)
     t_gen = time.perf_counter() - t_gen
+    if len(ql) == 0:
+        raise SystemExit(f"rank {rank}: the partition left this rank without pairs ({pairs} pairs over {world} ranks)")
     cells = int(shard.nominal_cells(ql, tl, W_BAND).sum())
+    total_batch_cells = 0.0
     if strong:
         loads = np.zeros(world, np.float64)
         loads[rank] = cells
@@ -220,7 +255,7 @@ def main():
     b.upload(stream)
     eng.synchronize() if stream is None else torch.cuda.synchronize()
 
-    kev = [(eng.event(), eng.event()) for _ in range(a.steps)]
+    kev = [(eng.event(), eng.event()) for _ in range(steps)]
 
     def step(i=None):
         if i is not None:
@@ -230,7 +265,7 @@ def main():
         if i is not None:
             eng.set_kernel_events(None, None)
         if use_dist and strong:
-            return shard.gather_results_tensor(res_t, idx_t, a.pairs, dist, torch)     # RCCL: 16 B per pair, input order restored
+            return shard.gather_results_tensor(res_t, idx_t, pairs, dist, torch)     # RCCL: 16 B per pair, input order restored
         if use_dist:
             dist.all_gather_into_tensor(gathered, res_t)       # RCCL: 12 B per pair, the only exchange
         else:
@@ -243,12 +278,12 @@ def main():
         else:
             eng.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     sync()
     t0 = time.perf_counter()
     last = None
-    for i in range(a.steps):
+    for i in range(steps):
         last = step(i)
     sync()
     elapsed = time.perf_counter() - t0
@@ -282,11 +317,90 @@ def main():
     kinds = b.pair_kinds(stream)            # how the last step's pairs were routed between the kernels
     sched = b.schedule_info(stream)         # (static preemptive schedule used, steps per lane group, lane groups used)
     sst = b.step_stats(stream)              # int16 kernel: (value wave-steps, key wave-steps, pairs started over, pairs started)
-    kms = [eng.elapsed_ms(e0, e1) for e0, e1 in kev] if a.steps else [float("nan")]
-    kernel_ms = float(np.mean(kms))
+    kms = [eng.elapsed_ms(e0, e1) for e0, e1 in kev] if steps else [float("nan")]
     G, S = eng.last_config()
     kind, Gd, Sd = b.kernel_choice(stream)  # which candidate kernel the device picked for the plain pairs
     kname = f"agatha::align16_kernel<{Gd},{Sd // 2}>" if kind == "int16" else f"agatha::align_kernel<{Gd},{Sd},false>"
+    gpu_res = None
+    if not use_dist:
+        gpu_res = tuple(np.array(b.res_host[j][:b.n]) for j in range(3))      # downloaded by the last step
+    n_local = b.n
+    b.free()
+    return dict(config=config, cfg=cfg, pairs=pairs, scaling=scaling, steps=steps, warmup=warmup, n_run_frac=n_run_frac,
+                elapsed=elapsed, total_cells=total_cells, total_pairs=total_pairs, cells_rank0=cells, n_local=n_local,
+                abytes=abytes, kernel_ms=float(np.mean(kms)), kinds=kinds, sched=sched, sst=sst, int32_shape=(G, S), kind=kind,
+                Gd=Gd, Sd=Sd, kname=kname, imbalance=imbalance, strong_check=strong_check, t_gen=t_gen, gpu_res=gpu_res,
+                host_batch=(qb, tb, qo, to, ql, tl), W=W_BAND, Z=Z)
+
+
+def workload_text(L):
+    cfg = L["cfg"]
+    return (f"{L['config']}: {L['pairs']} {cfg['text']}, " + (f"{L['n_run_frac']:.0%} of the DP-row sequences with a run of N, " if L["n_run_frac"] > 0 else "") +
+            ("ONE batch sharded over the GPUs (LPT by nominal cells)" if L["scaling"] == "strong" else "per GPU") +
+            f", m{cfg['scoring']['m']} x{cfg['scoring']['x']} q{cfg['scoring']['q']} r{cfg['scoring']['r']} w{L['W']} z{L['Z']} s3 "
+            f"(BASELINE.json configs[{int(L['config'][1])}])")
+
+
+def main():
+    rc = maybe_spawn_ranks(sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=0, help="pairs (per GPU when weak scaling); default: the config's own size")
+    ap.add_argument("--config", default="C1", choices=sorted(CONFIGS), help="workload shape of BASELINE.json (default C1 = configs[1], the headline)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank aligns its own batch; strong: ONE batch, LPT-sharded over the ranks, results gathered")
+    ap.add_argument("--n-run-frac", type=float, default=0.0, help="fraction of the DP-row sequences (file 1: reference pieces) that carry a run of N (50-1000 bases)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gasal-api", action="store_true", help="skip the timing of the CLI / GASAL API by the reference's raw.log protocol")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the sustained stream/batch-manager leg (gasal_aln_async over 16 batches)")
+    ap.add_argument("--strong-pairs", type=int, default=100000, help="N > 1: pairs of the ONE sharded batch of the `strong` object (BASELINE configs[2]); 0 = no strong leg")
+    a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    if a.pairs <= 0:
+        a.pairs = cfg["pairs"]
+
+    # RCCL / HIP print banners to fd 1 on some boxes (NCCL_DEBUG=VERSION): keep stdout clean for the ONE JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    ctx = Ctx()
+    ctx.rank = rank = int(os.environ.get("RANK", "0"))
+    ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx.use_dist = use_dist = "WORLD_SIZE" in os.environ
+    ctx.torch = ctx.dist = torch = dist = None
+    n_ranks_rccl = None
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ctx.torch, ctx.dist = torch, dist
+        n_ranks_rccl = dist.get_world_size()
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
+
+    import agatha_amd
+
+    ctx.eng = eng = agatha_amd.Engine(local_rank)
+    ctx.stream = None
+    if use_dist:
+        ctx.stream = torch.cuda.current_stream().cuda_stream   # run on torch's stream so the gather is ordered behind align
+
+    L = run_leg(ctx, a.config, a.pairs, a.scaling, a.steps, a.warmup, a.n_run_frac)
+    strong_leg = None
+    if use_dist and world > 1 and a.scaling == "weak" and a.strong_pairs > 0:
+        # the sharded batch BASELINE.json names for 8 GPUs (configs[2]: 100 000 HiFi pairs), strong scaling, in the same run
+        strong_leg = run_leg(ctx, "C2", a.strong_pairs, "strong", min(a.steps, 3) if a.steps else 0, 1)
+
+    kernel_ms, cells, kind, kname = L["kernel_ms"], L["cells_rank0"], L["kind"], L["kname"]
+    abytes, strong = L["abytes"], a.scaling == "strong"
+    W_BAND, Z = L["W"], L["Z"]
     # HBM bytes per launch measured with rocprofv3 PMC counters in a separate profiled run of this same command
     # (profiles/latest_pmc.json, written by tools/collate_profile.py); only quoted when it was taken on the kernel, the
     # workload and the schedule that just ran -- a stale file gives null, not a wrong number
@@ -297,7 +411,7 @@ def main():
         same_kernel = pm.get("kernel", "").replace(" ", "").startswith(kname.rstrip(">").replace(" ", "") + ",") or \
             pm.get("kernel", "").replace(" ", "") == kname.replace(" ", "")
         if pm.get("pairs") == a.pairs and pm.get("config", "C1") == a.config and same_kernel and not strong and \
-                bool(pm.get("preemptive_schedule", False)) == bool(sched[0]):
+                bool(pm.get("preemptive_schedule", False)) == bool(L["sched"][0]):
             traffic = float(pm["hbm_bytes_per_launch"])
             issued = pm.get("valu_insts_per_launch")
             conflicts = pm.get("lds_bank_conflict_cycles")
@@ -305,11 +419,13 @@ def main():
         pass
 
     if rank == 0:
+        elapsed, sst, sched, kinds = L["elapsed"], L["sst"], L["sched"], L["kinds"]
+        G, S = L["int32_shape"]
         ms_per_step = elapsed / max(a.steps, 1) * 1e3
         out = {
             "metric": "GCUPS (banded DP cells/s), 10 kb ONT pairs, band=751, z=400" if a.config == "C1" else
                       f"GCUPS (banded DP cells/s), BASELINE.json config {a.config}, band={W_BAND}, z={Z}",
-            "value": total_cells * a.steps / elapsed / 1e9,
+            "value": L["total_cells"] * a.steps / elapsed / 1e9,
             "unit": "GCUPS",
             "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup,
@@ -319,16 +435,15 @@ def main():
             "vs_baseline": None,
             "dtype": kind,
             "data": "synthetic",
-            "config": {"workload": f"{a.config}: {a.pairs} {cfg['text']}, " + (f"{a.n_run_frac:.0%} of the DP-row sequences with a run of N, " if a.n_run_frac > 0 else "") + ("ONE batch sharded over the GPUs (LPT by nominal cells)" if strong else "per GPU") +
-                                   f", m{cfg['scoring']['m']} x{cfg['scoring']['x']} q{cfg['scoring']['q']} r{cfg['scoring']['r']} w{W_BAND} z{Z} s3 "
-                                   f"(BASELINE.json configs[{int(a.config[1])}])",
-                       "pairs_per_gpu": b.n, "host_seconds_to_make_the_rank0_batch": round(t_gen, 2), "shard_imbalance_max_over_mean": imbalance, "strong_scaling_check": strong_check, "lanes_per_pair": Gd, "slots_per_lane": Sd, "kernel": kname,
+            "config": {"workload": workload_text(L),
+                       "pairs_per_gpu": L["n_local"], "host_seconds_to_make_the_rank0_batch": round(L["t_gen"], 2), "shard_imbalance_max_over_mean": L["imbalance"], "strong_scaling_check": L["strong_check"], "lanes_per_pair": L["Gd"], "slots_per_lane": L["Sd"], "kernel": kname,
+                       "n_ranks_seen_by_rccl": n_ranks_rccl,
                        "int32_fallback_kernel": f"agatha::align_kernel<{G},{S}>",
                        "pairs_plain_other_letters_int32_takeover_rank0": list(kinds),
                        "preemptive_schedule_rank0": {"used": sched[0], "steps_per_lane_group": sched[1], "lane_groups": sched[2]},
                        "int16_steps_rank0": {"value_wave_steps": sst[0], "key_wave_steps": sst[1], "pairs_started_over": sst[2], "pairs_started": sst[3], "debug": list(sst[4:])},
                        "step": "pack + sort + align + D2H results" + (" + RCCL all-gather" if use_dist else "")},
-            "pairs_per_s": total_pairs * a.steps / elapsed,
+            "pairs_per_s": L["total_pairs"] * a.steps / elapsed,
             "kernel_ms": kernel_ms,
             "kernel_gcups_rank0": cells / kernel_ms / 1e6,
             "roofline": {"bound": "hbm", "achieved": abytes / kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -344,8 +459,9 @@ def main():
                               "ops_per_cell": OPS_PER_CELL[kind],
                               "frac_vs_guide_2cycle_issue": cells * OPS_PER_CELL[kind] / kernel_ms / 1e9 / VALU_GUIDE_PEAK_TOPS,
                               "frac_at_value_step_count": (cells * OPS_PER_CELL_VALUE_STEPS / kernel_ms / 1e9 / VALU_PEAK_TOPS) if kind == "int16" else None,
-                              "peak_source": "measured: profiles/r03_v0/valu_rate.txt (4 cycles per wave64 instruction for every op of the kernel); "
-                                             "frac_vs_guide_2cycle_issue prices the same ops against the guide's 2-cycle issue",
+                              "peak_source": "measured: profiles/r04_v0/valu_class.txt (4 cycles per wave64 instruction for every packed / SDWA / VOP3 op the "
+                                             "kernel is made of; the 2-cycle class -- v_add/sub/and/or/xor, 16-bit VOP2 -- gains < 4 % inside this "
+                                             "kernel's mixed stream); frac_vs_guide_2cycle_issue prices the same ops against the guide's 2-cycle issue",
                               "issued_lane_ops_per_cell": (issued * 64.0 / cells) if issued else None,
                               "lds_bank_conflict_cycles": conflicts,
                               "note": "lane-ops the recurrence itself needs per cell x cells/s over the measured VALU issue "
@@ -353,6 +469,17 @@ def main():
                                       "round 2's count (10 per cell pair with H : column keys) so that rounds compare; value steps "
                                       "need 8 per cell pair (frac_at_value_step_count)"},
         }
+        if strong_leg is not None:
+            SL = strong_leg
+            out["strong"] = {"metric": f"GCUPS, ONE batch of {SL['pairs']} BASELINE configs[2] pairs sharded over {world} GPUs",
+                             "value": SL["total_cells"] * SL["steps"] / SL["elapsed"] / 1e9, "unit": "GCUPS", "n_gpus": world,
+                             "steps": SL["steps"], "warmup": SL["warmup"], "ms_per_step": SL["elapsed"] / max(SL["steps"], 1) * 1e3,
+                             "pairs_per_s": SL["total_pairs"] * SL["steps"] / SL["elapsed"], "scaling": "strong",
+                             "workload": workload_text(SL), "pairs_rank0": SL["n_local"], "kernel": SL["kname"], "kernel_ms_rank0": SL["kernel_ms"],
+                             "shard_imbalance_max_over_mean": SL["imbalance"], "strong_scaling_check": SL["strong_check"],
+                             "host_seconds_to_make_the_rank0_shard": round(SL["t_gen"], 2), "n_ranks_seen_by_rccl": n_ranks_rccl,
+                             "step": "pack + sort + align + RCCL all-gather of results and pair ids (input order restored on every rank)"}
+        qb, tb, qo, to, ql, tl = L["host_batch"]
         if world == 1 and not a.no_gasal_api and a.config in ("C0", "C1"):
             # The same batch through the product's real entry point, by the reference's own protocol (AGAThA.sh:44,52: `manual -p`,
             # sum of raw.log): FASTA files -> CLI -> gasal_aln_async on two streams per host thread -> kernel ms per batch written
@@ -363,24 +490,34 @@ def main():
                 qs_host = [qb[int(o):int(o) + int(l)].tobytes() for o, l in zip(qo, ql)]
                 ts_host = [tb[int(o):int(o) + int(l)].tobytes() for o, l in zip(to, tl)]
                 runs = gasal_api_timing.time_config(qs_host, ts_host, cfg["scoring"], W_BAND, Z, combos=((a.pairs, 1), (8192, 1)))
-                del qs_host, ts_host
                 for r in runs:
                     r.pop("per_batch"); r.pop("score_log")
                 out["gasal_api"] = {"protocol": "agatha_amd/manual -p (reference AGAThA.sh:44,52, gasal_align.cu:219-236): kernel ms per batch as written to raw.log by libgasal_amd.so; two streams per host thread",
                                     "runs": runs,
                                     "kernel_ms_per_batch_of_all_pairs": runs[0]["kernel_ms_sum"],
                                     "vs_kernel_ms": runs[0]["kernel_ms_sum"] / kernel_ms if kernel_ms else None}
+                if not a.no_pipeline and a.config == "C1":
+                    # the stream / batch manager over many batches (wall time of {H2D, pack, sort, align, D2H},
+                    # stream-overlapped; reference gasal_align.cu:144-162,254-266 + test_prog.cpp:273-375)
+                    out["gasal_api"]["pipeline"] = gasal_api_timing.time_pipeline(qs_host, ts_host, cfg["scoring"], W_BAND, Z, kernel_gcups=cells / kernel_ms / 1e6)
+                del qs_host, ts_host
             except Exception as e:          # (a missing CLI binary must not cost the bench line)
                 out["gasal_api"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
-            gpu_res = tuple(np.array(b.res_host[j][:b.n]) for j in range(3))      # downloaded by the last step
             out["cpu_baseline"] = cpu_baseline(qb, tb, qo, to, ql, tl, dict(s=3, z=Z, w=W_BAND, **cfg["scoring"]), W_BAND,
-                                               gpu_res=gpu_res)
+                                               gpu_res=L["gpu_res"])
+            eff = out["cpu_baseline"].pop("effective", None)
+            if eff is not None and "error" in eff:
+                out["effective_cells"] = eff
+            elif eff is not None:
+                # effective cells = the anti-diagonals up to each pair's z-drop stop (from the CPU side, the
+                # checker); both rates are quoted, `value` stays the nominal one (the reference's own count)
+                out["effective_cells"] = dict(eff, gcups=eff["effective_cells"] / eff["nominal_cells"] * out["value"],
+                                              kernel_gcups=eff["effective_cells"] / eff["nominal_cells"] * cells / kernel_ms / 1e6)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    b.free()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

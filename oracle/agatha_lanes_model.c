@@ -43,7 +43,9 @@ typedef struct {
     int32_t xh[MAXS + 1][8], xe[MAXS + 1][8];
     int xr[MAXS + 1];
     int32_t A[15];
-    int32_t AV[2][15];      /* value steps of the int16 kernel: maxima of H alone, per half (even / odd slots) of the lane */
+    int32_t AV[2][15];      /* the int16 kernel's maxima of H alone, per half (even / odd slots) of the lane: this step's own cells */
+    int32_t CAR[2][7];      /* ... and what the previous step's blocks left on this step's anti-diagonals 0..6 (carried) */
+    int32_t bhi[MAXS], blo[MAXS];   /* value steps: largest / smallest-over-anti-diagonals boundary value of the slot's block (see below) */
 } lane_t;
 
 static void init_col(lane_t *ln, int s, int r, int R, int prl, int w, int gapoe, int ge, const uint32_t *pt)
@@ -293,14 +295,27 @@ static void init_col16(lane_t *ln, int s, int r, int R, int prl, int w, int gapo
     ln->rcur[s] = r;
 }
 
-/* Value steps (align16_body.inc, FAST): with agatha_lanes16_margin > 0 every step except a pair's last `margin` ones only
- * tracks the VALUES of the anti-diagonal maxima -- per lane and half, as the kernel's packed accumulators do -- and may decide
- * nothing but the running maximum: it needs the "calm" test (every anti-diagonal maximum, bounded from below by the largest
- * over lanes and halves of a half's smallest accumulator, within z of the running maximum, well inside its zone, inside the
- * pair).  A step that is not calm, a key step that needs cells it does not know (the maximum rose on a value step, or the
- * step's carried accumulators were values: "stale"), or an end without the cell of the maximum returns 2: the caller runs
- * the pair again on key steps only -- what the kernel does by starting the pair over.  The model keeps exact keys all along;
- * what it checks is the DECISION logic: whenever it returns 0 with a margin, the result must be the oracle's. */
+/* Value steps (align16_body.inc, FAST), round 4: with agatha_lanes16_margin > 0 every step from the pair's second one to the
+ * start of its window of key steps computes NO anti-diagonal maxima inside the block.  It only looks, behind each block, at the
+ * 15 cells of the block's last row and last column -- state the kernel holds in registers anyway (the column state H of row 7, the
+ * row hand-off of column 7) -- which lie on the block's cell anti-diagonals 7..14:
+ *   HI = the largest of them over the group (rows behind a query's end included) bounds EVERY cell of the step's blocks from
+ *        above once `slack` = 7 max(mismatch, 1) is added: H(i+1, j+1) >= H(i, j) + s, so a cell is at most 7 diagonal moves
+ *        below a cell of the last row or column; taken in the frame of anti-diagonal 8i + 7 (the earliest) it can only be too large.
+ *   LO = the largest, over lanes and slots, of a block's SMALLEST anti-diagonal value (the larger of its one or two valid cells
+ *        on each of 7..14): a lower bound of the maximum of every anti-diagonal 8i + 7 .. 8i + 14 (the block that holds the best
+ *        cells has cells on all eight); taken in the frame of 8i + 14 (the latest) it can only be too small.
+ * `best` becomes an UPPER BOUND of the running maximum on a value step that may have raised it (pos_known = 0: neither its cell nor its
+ * exact value is known); it is exact again as soon as a key step sees a cell above it (everything before that cell is <= the bound).
+ * A value step is calm -- may decide "nothing but the running maximum moves" -- when LO of this step AND of the previous one
+ * (the anti-diagonals 8i .. 8i + 6 have their boundary cells in the previous step's blocks) are within z of the bound, well inside
+ * their zone, inside the pair.  A step that is not calm, a key step that needs cells it does not know, or an end without the cell
+ * of the maximum returns 2: the caller runs the pair again on key steps only -- what the kernel does by starting the pair over.
+ * Where the two forms meet: the first key step behind value steps ("stale") knows of its anti-diagonals 0..6 only the lower bound LO
+ * of the step before; the first value step behind key steps takes lower and upper bound of those anti-diagonals from the carried
+ * keys.  Steps i <= 0 are key steps (the anti-diagonals 0..6 of a pair have no boundary cell before them).
+ * The model keeps exact keys all along; what it checks is the DECISION logic: whenever it returns 0 with a margin, the result
+ * must be the oracle's. */
 __thread int agatha_lanes16_margin = 0;
 
 int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_params_t *pr,
@@ -330,7 +345,11 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
         for (int s = 0; s < S; s++) init_col16(&L[k], s, k * S + s, R, prl, w, gapoe, ge, base, pt);
         for (int s = 0; s <= S; s++) L[k].xr[s] = -2;
         for (int x = 0; x < 15; x++) { L[k].A[x] = INT_MIN; L[k].AV[0][x] = INT_MIN; L[k].AV[1][x] = INT_MIN; }
+        for (int x = 0; x < 7; x++) { L[k].CAR[0][x] = INT_MIN; L[k].CAR[1][x] = INT_MIN; }
     }
+    const int slack = 7 * imax(b, 1);
+    int ewin = 2 * (pql < prl ? pql : prl) - 1 - margin - ((pql + prl) >> 7);      /* first step of the window of key steps */
+    int64_t lo_prev_abs = INT_MIN;      /* value steps: lower bound (absolute score) of the maxima of this step's anti-diagonals 0..6 */
     int best = 0, best_t = 0, best_q = 0, stopped = 0, bail = 0;
     int i = 0, y = 0, final = 0, cb_prev = 0;
     int ss = 0, se = imin(imin(prl - 1, sw - 1), ((sw - 1) * 8 + 7 + w) / 2 / 8);
@@ -348,6 +367,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 const int r = ln->rcur[s], q = i - r;
                 const int cs = imax(0, r - W), ce = imin(pql - 1, r + W);
                 const int active = !final && r < prl && q >= cs && q <= ce && r >= ss && r <= se;
+                ln->bhi[s] = INT_MIN; ln->blo[s] = INT_MIN;
                 if (!active) { ln->xr[s + 1] = -2; continue; }
                 if (y == 0)
                     for (int m = 0; m < 8; m++) if (8 * r + m >= R) { ln->h[s][m] = L16_NEG; ln->f[s][m] = L16_NEG; }
@@ -378,7 +398,10 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                     if (out_r0) { f[m] = L16_OUT; if (m > 0) h[m - 1] = L16_OUT; }      /* its F and its diagonal */
                 }
                 for (int il = 0; il < 8; il++) {
-                    const int qb = (qword >> (28 - 4 * il)) & 15;       /* N beyond the query: packing pads with N */
+                    int qb = (qword >> (28 - 4 * il)) & 15;             /* N beyond the query: packing pads with N */
+                    /* (rows behind the query's end: the kernel's value steps read the N padding as class 3 = G, class_word();
+                     *  nothing valid depends on them, but the upper bound HI of a value step sees them) */
+                    if (margin > 0 && il >= nrows && qb == N_VALUE) qb = 7;
                     int32_t t[8];
                     for (int jl = 0; jl < 8; jl++) {
                         const int rb = (rword >> (28 - 4 * jl)) & 15;
@@ -406,6 +429,19 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                     }
                     oh[il] = h[7]; oe[il] = e;
                 }
+                {
+                    /* the block's last row (7, x) = h[x] and last column (x, 7) = oh[x], cell anti-diagonal 7 + x, as computed
+                     * (before the stale values of a lower edge block go into the hand-off) */
+                    int32_t hi = INT_MIN, lo = INT_MAX;
+                    for (int x = 0; x < 8; x++) {
+                        hi = imax(hi, imax(h[x], oh[x]));
+                        int32_t v = INT_MIN;                    /* valid cells only: rows that exist */
+                        if (nrows == 8) v = imax(v, h[x]);
+                        if (x < nrows) v = imax(v, oh[x]);
+                        lo = imin(lo, v);
+                    }
+                    ln->bhi[s] = hi; ln->blo[s] = lo;
+                }
                 for (int il = 0; il < 8; il++)
                     if (il - 7 > tl) {       /* the same VALUE is handed on for a row il - (tl + 7) anti-diagonals further down */
                         const int32_t sv = oh[imax(0, tl + 7)];
@@ -424,33 +460,66 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 memcpy(L[k].xh[0], th[src], sizeof(th[src])); memcpy(L[k].xe[0], te[src], sizeof(te[src])); L[k].xr[0] = tr[src];
             }
         }
-        /* ---- value steps: the calm test on values alone, the mode of this step ---- */
+        /* ---- value steps: the mode of this step, the calm test ---- */
         /* (the kernel's window of key steps, align16_body.inc `ewin`: from `margin` + 1/128 of the steps before the block anti-diagonal of
-         *  the corner the shorter sequence ends in, to the pair's end) */
-        const int fast = margin > 0 && i < 2 * (pql < prl ? pql : prl) - 1 - margin - ((pql + prl) >> 7);
+         *  the corner the shorter sequence ends in, to the pair's end; and the pair's first step) */
+        /* (the bound of a value step lies up to slack + 7 ge above the running maximum, and the key steps must see the score rise by
+         *  more than that: every 64 steps the window is widened by the steps that takes at the pair's rate so far, 3/2 of them) */
+        if (margin > 0 && i > 0 && (i & 63) == 0 && best > 0)
+            ewin = imin(ewin, 2 * (pql < prl ? pql : prl) - 1 - margin - ((pql + prl) >> 7) - (int)(((int64_t)3 * (slack + 7 * ge) * i) / (2 * (int64_t)best)));
+        const int fast = margin > 0 && i >= 1 && i < ewin;
         int calm = 0, stale = 0;
+        int32_t HI = INT_MIN;
         if (margin > 0) {
-            int32_t lo8 = INT_MIN, mk = INT_MIN;
-            for (int k = 0; k < G; k++)
-                for (int hf = 0; hf < 2; hf++) {
-                    int32_t lo = INT_MAX, hi = INT_MIN;
-                    for (int x = 0; x < 8; x++) {
-                        const int32_t a = L[k].AV[hf][x];
-                        const int32_t v = a == INT_MIN ? INT_MIN : a + (7 - x) * ge;      /* the frame of the step's last anti-diagonal */
-                        if (v < lo) lo = v;
-                        if (v > hi) hi = v;
-                    }
-                    if (lo > lo8) lo8 = lo;
-                    if (hi > mk) mk = hi;
-                }
-            const int64_t base_i = (int64_t)base - (int64_t)ge * (8 * i + 7);
-            calm = !final && (8 * i + 7 < lim) && lo8 != INT_MIN && lo8 >= L16_LO + spread + L16_DELTA + 7 * ge &&
-                   lo8 + base_i >= NEG_INF2 + spread && (z < 0 || imax(best, (int)(mk + base_i)) - (int)(lo8 + base_i) <= z);
             stale = !fast && prev_fast;
             if (fast) {
+                if (!prev_fast) {
+                    /* first value step behind key steps: what the key step's blocks left on this step's anti-diagonals 0..6 */
+                    int32_t clo = INT_MIN, chi = INT_MIN;
+                    for (int k = 0; k < G; k++)
+                        for (int hf = 0; hf < 2; hf++) {
+                            int32_t lo = INT_MAX, hi = INT_MIN;
+                            for (int x = 0; x < 7; x++) { lo = imin(lo, L[k].CAR[hf][x]); hi = imax(hi, L[k].CAR[hf][x]); }
+                            clo = imax(clo, lo); chi = imax(chi, hi);
+                        }
+                    lo_prev_abs = clo == INT_MIN ? INT_MIN : (int64_t)clo + base - (int64_t)ge * (8 * i + 6);
+                    if (chi != INT_MIN && (int64_t)chi + base - (int64_t)ge * (8 * i) > best) { best = (int)((int64_t)chi + base - (int64_t)ge * (8 * i)); pos_known = 0; }
+                }
+                int32_t LO = INT_MIN;
+                for (int k = 0; k < G; k++)
+                    for (int sx = 0; sx < S; sx++) { LO = imax(LO, L[k].blo[sx]); HI = imax(HI, L[k].bhi[sx]); }
+                const int64_t lo_abs = LO == INT_MIN ? INT_MIN : (int64_t)LO + base - (int64_t)ge * (8 * i + 14);
+                const int64_t ub = HI == INT_MIN ? INT_MIN : (int64_t)HI + base - (int64_t)ge * (8 * i + 7) + slack;
+                const int64_t nb = ub > best ? ub : best, lo_both = lo_abs < lo_prev_abs ? lo_abs : lo_prev_abs;
+                calm = !final && (8 * i + 7 < lim) && LO != INT_MIN && lo_prev_abs != INT_MIN && LO >= L16_LO + spread + L16_DELTA + 7 * ge &&
+                       lo_abs >= NEG_INF2 + spread && (z < 0 || nb - lo_both <= z);
                 if (!calm) { again = 1; break; }
-                if ((int)(mk + base_i) > best) { best = (int)(mk + base_i); pos_known = 0; }
-            } else if (!calm && (stale || !pos_known)) { again = 1; break; }
+                if (ub > best) { best = (int)ub; pos_known = 0; }
+                lo_prev_abs = lo_abs;
+            } else {
+                int32_t lo8 = INT_MIN, mk = INT_MIN;
+                for (int k = 0; k < G; k++)
+                    for (int hf = 0; hf < 2; hf++) {
+                        int32_t lo = INT_MAX, hi = INT_MIN;
+                        for (int x = 0; x < 8; x++) {
+                            int32_t a = L[k].AV[hf][x];
+                            if (x < 7) {
+                                /* (stale: the value steps carried no maxima, only the lower bound of the step before) */
+                                const int32_t c = !stale ? L[k].CAR[hf][x] : (lo_prev_abs == INT_MIN ? INT_MIN : (int32_t)(lo_prev_abs - base + (int64_t)ge * (8 * i + x)));
+                                a = imax(a, c);
+                            }
+                            const int32_t v = a == INT_MIN ? INT_MIN : a + (7 - x) * ge;      /* the frame of the step's last anti-diagonal */
+                            if (v < lo) lo = v;
+                            if (v > hi) hi = v;
+                        }
+                        if (lo > lo8) lo8 = lo;
+                        if (hi > mk) mk = hi;
+                    }
+                const int64_t base_i = (int64_t)base - (int64_t)ge * (8 * i + 7);
+                calm = !final && (8 * i + 7 < lim) && lo8 != INT_MIN && lo8 >= L16_LO + spread + L16_DELTA + 7 * ge &&
+                       lo8 + base_i >= NEG_INF2 + spread && (z < 0 || imax(best, (int)(mk + base_i)) - (int)(lo8 + base_i) <= z);
+                if (!calm && (stale || !pos_known)) { again = 1; break; }
+            }
             prev_fast = fast;
         }
         int hi_rep = INT_MIN;
@@ -459,7 +528,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
             for (int k = 0; k < G; k++) v = imax(v, L[k].A[x]);
             const int d = 8 * i + x;
             if (v != INT_MIN && (v >> K) >= L16_LO) hi_rep = imax(hi_rep, v >> K);
-            if (fast) continue;                 /* a value step looks at no anti-diagonal by itself */
+            if (fast) { hi_rep = HI; continue; }    /* a value step looks at no anti-diagonal by itself (its rebase follows the boundary cells) */
             if (!final && d >= lim) continue;
             int H, c;
             if (v == INT_MIN || (v >> K) < L16_GLO) { H = -32768; c = 0; }      /* empty, or only out-of-band cells */
@@ -476,8 +545,9 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
         }
         if (bail || stopped || final) break;
         for (int k = 0; k < G; k++) {
-            for (int x = 0; x < 7; x++) { L[k].A[x] = L[k].A[8 + x]; L[k].AV[0][x] = L[k].AV[0][8 + x]; L[k].AV[1][x] = L[k].AV[1][8 + x]; }
-            for (int x = 7; x < 15; x++) { L[k].A[x] = INT_MIN; L[k].AV[0][x] = INT_MIN; L[k].AV[1][x] = INT_MIN; }
+            for (int x = 0; x < 7; x++) { L[k].A[x] = L[k].A[8 + x]; L[k].CAR[0][x] = L[k].AV[0][8 + x]; L[k].CAR[1][x] = L[k].AV[1][8 + x]; }
+            for (int x = 7; x < 15; x++) L[k].A[x] = INT_MIN;
+            for (int x = 0; x < 15; x++) { L[k].AV[0][x] = INT_MIN; L[k].AV[1][x] = INT_MIN; }
         }
         cb_prev = cb;
         /* rebase: keep the representation of the running maximum small */
@@ -493,7 +563,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                     for (int m = 0; m < 8; m++) { ln->xh[s][m] = REB(ln->xh[s][m]); ln->xe[s][m] = REB(ln->xe[s][m]); }
                 for (int x = 0; x < 7; x++) if (ln->A[x] != INT_MIN) ln->A[x] = imax(ln->A[x] - (L16_DELTA << K), imin(ln->A[x], ((L16_LO + 32768) << K) - 1 - (32768 << K)));
                 for (int hf = 0; hf < 2; hf++)
-                    for (int x = 0; x < 7; x++) if (ln->AV[hf][x] != INT_MIN) ln->AV[hf][x] = REB(ln->AV[hf][x]);
+                    for (int x = 0; x < 7; x++) if (ln->CAR[hf][x] != INT_MIN) ln->CAR[hf][x] = REB(ln->CAR[hf][x]);
             }
         }
         for (int k = 0; k < G; k++)

@@ -458,8 +458,10 @@ void agatha_steps_stats_batch(const uint8_t *qbatch, const uint8_t *tbatch, cons
 /* Textbook model: exact |i-j|<=w band, same recurrence/tie-break/z-drop, no block quirks.      */
 /* Used only to quantify how often the block-granular band matters (SURVEY.md App. B #1,#2).    */
 /* ------------------------------------------------------------------------------------------ */
-void agatha_model_exactband(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr,
-                            oracle_result_t *out)
+/* (stop_diag: the last cell anti-diagonal the z-drop walk looked at -- Q + R - 2 when it never stopped; what bench.py's
+   "effective cells" count up to) */
+void agatha_model_exactband_stop(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr,
+                                 oracle_result_t *out, int *stop_diag)
 {
     const int a = pr->match, b = pr->mismatch, gapoe = pr->gap_open + pr->gap_extend, ge = pr->gap_extend;
     const int w = pr->band_width, z = pr->z_threshold;
@@ -497,12 +499,21 @@ void agatha_model_exactband(const char *qs, int Q, const char *rs, int R, const 
         if (jlo > 0) Hrow[jlo] = NEG_INF2;   /* cell left of the band on the next row */
     }
     zstate_t zs = {0, 0, 0, 0};
+    int last = -1;
     for (int d = 0; d < Q + R - 1 && !zs.stopped; d++) {
         int H = dh[d] == INT_MIN ? -32768 : dh[d];
         zdrop_check(&zs, H, dh[d] == INT_MIN ? 0 : dc[d], d, z, ge);
+        last = d;
     }
+    if (stop_diag) *stop_diag = last;
     out->score = zs.best; out->query_end = zs.best_q; out->target_end = zs.best_t;
     free(Hrow); free(dh); free(qc); free(rc);
+}
+
+void agatha_model_exactband(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr,
+                            oracle_result_t *out)
+{
+    agatha_model_exactband_stop(qs, Q, rs, R, pr, out, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -558,6 +569,19 @@ void agatha_oracle_pack(const uint8_t *unpacked, uint32_t nbytes, uint32_t *pack
         for (int k = 0; k < 8; k++) v |= (uint32_t)(unpacked[8 * wi + k] & 15) << (28 - 4 * k);
         packed[wi] = v;
     }
+}
+
+/* in-band cells of a pair on the cell anti-diagonals 0 .. stop_diag (exact band |i - j| <= w): the "effective cells" of
+   SURVEY.md 8(d) for a pair whose z-drop walk ended on stop_diag */
+int64_t agatha_cells_upto_diag(int Q, int R, int w, int stop_diag)
+{
+    int64_t n = 0;
+    if (Q <= 0 || R <= 0) return 0;
+    for (int d = 0; d <= stop_diag && d < Q + R - 1; d++) {
+        const int lo = imax(imax(0, d - (R - 1)), (d - w + 1) >> 1), hi = imin(imin(Q - 1, d), (d + w) >> 1);
+        if (hi >= lo) n += hi - lo + 1;
+    }
+    return n;
 }
 
 /* nominal in-band cells of a pair, SURVEY.md 8(d) */

@@ -30,11 +30,12 @@ static inline int imin_(int a, int b) { return a < b ? a : b; }
 static inline int imax_(int a, int b) { return a > b ? a : b; }
 
 /* returns 0 on success, -1 if the pair is outside the int16 domain (caller falls back to the scalar model) */
-int ksw_style_avx2_pair(const char *qs, int Q, const char *rs, int R, const ksw_params_t *pr, int32_t *out3)
+static int ksw_style_avx2_pair_stop(const char *qs, int Q, const char *rs, int R, const ksw_params_t *pr, int32_t *out3, int *stop_diag)
 {
     const int a = pr->match, b = pr->mismatch, oe = pr->gap_open + pr->gap_extend, ge = pr->gap_extend;
     const int w = pr->band_width, z = pr->z_threshold;
     out3[0] = out3[1] = out3[2] = 0;
+    if (stop_diag) *stop_diag = -1;
     if (Q <= 0 || R <= 0) return 0;
     if ((long)a * imin_(Q, R) >= 32000 || 16384 + (long)(2 * w + 4) * ge + oe + b >= 32000) return -1;
 
@@ -65,6 +66,7 @@ int ksw_style_avx2_pair(const char *qs, int Q, const char *rs, int R, const ksw_
     int best = 0, best_t = 0, best_q = 0, stopped = 0;
     const int lim = Q + R - 1;
     for (int d = 0; d < lim && !stopped; d++) {
+        if (stop_diag) *stop_diag = d;
         const int lo = imax_(imax_(0, d - (R - 1)), (d - w + 1) >> 1);      /* ceil((d-w)/2) */
         const int hi = imin_(imin_(Q - 1, d), (d + w) >> 1);                /* floor((d+w)/2) */
         /* boundary cells of THIS diagonal: (-1, d+1) and (d+1, -1) */
@@ -146,15 +148,22 @@ int ksw_style_avx2_pair(const char *qs, int Q, const char *rs, int R, const ksw_
     free(buf); free(rrev);
     return 0;
 }
+int ksw_style_avx2_pair(const char *qs, int Q, const char *rs, int R, const ksw_params_t *pr, int32_t *out3)
+{
+    return ksw_style_avx2_pair_stop(qs, Q, rs, R, pr, out3, NULL);
+}
 #else
 typedef struct { int32_t match, mismatch, gap_open, gap_extend, slice_width, z_threshold, band_width; } ksw_params_t;
 int ksw_style_avx2_pair(const char *qs, int Q, const char *rs, int R, const ksw_params_t *pr, int32_t *out3)
 { (void)qs; (void)Q; (void)rs; (void)R; (void)pr; (void)out3; return -1; }
+static int ksw_style_avx2_pair_stop(const char *qs, int Q, const char *rs, int R, const ksw_params_t *pr, int32_t *out3, int *stop_diag)
+{ (void)qs; (void)Q; (void)rs; (void)R; (void)pr; (void)out3; (void)stop_diag; return -1; }
 #endif
 
 /* from agatha_oracle.c */
 typedef struct { int32_t score, query_end, target_end; } oracle_result_t_;
 void agatha_model_exactband(const char *qs, int Q, const char *rs, int R, const void *pr, oracle_result_t_ *out);
+void agatha_model_exactband_stop(const char *qs, int Q, const char *rs, int R, const void *pr, oracle_result_t_ *out, int *stop_diag);
 
 void ksw_style_batch(const uint8_t *qbatch, const uint8_t *tbatch, const uint32_t *qoff, const uint32_t *toff,
                      const uint32_t *qlen, const uint32_t *tlen, int n, const ksw_params_t *pr, int threads,
@@ -174,6 +183,31 @@ void ksw_style_batch(const uint8_t *qbatch, const uint8_t *tbatch, const uint32_
             o[0] = r.score; o[1] = r.query_end; o[2] = r.target_end; fb++;
         }
         score[k] = o[0]; qend[k] = o[1]; tend[k] = o[2];
+    }
+    if (n_fallback) *n_fallback = fb;
+}
+
+/* the same, which also reports the cell anti-diagonal each pair's z-drop walk ended on (Q + R - 2: it never stopped):
+   bench.py's "effective cells"  */
+void ksw_style_batch_stops(const uint8_t *qbatch, const uint8_t *tbatch, const uint32_t *qoff, const uint32_t *toff,
+                           const uint32_t *qlen, const uint32_t *tlen, int n, const ksw_params_t *pr, int threads,
+                           int32_t *score, int32_t *qend, int32_t *tend, int32_t *stop_diag, int *n_fallback)
+{
+    int fb = 0;
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1) reduction(+:fb)
+#endif
+    for (int k = 0; k < n; k++) {
+        int32_t o[3];
+        int sd = -1;
+        const char *q = (const char *)qbatch + qoff[k], *t = (const char *)tbatch + toff[k];
+        if (ksw_style_avx2_pair_stop(q, (int)qlen[k], t, (int)tlen[k], pr, o, &sd) != 0) {
+            oracle_result_t_ r;
+            agatha_model_exactband_stop(q, (int)qlen[k], t, (int)tlen[k], pr, &r, &sd);
+            o[0] = r.score; o[1] = r.query_end; o[2] = r.target_end; fb++;
+        }
+        score[k] = o[0]; qend[k] = o[1]; tend[k] = o[2]; stop_diag[k] = sd;
     }
     if (n_fallback) *n_fallback = fb;
 }

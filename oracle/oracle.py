@@ -54,6 +54,11 @@ def lib():
         _lib.ksw_style_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p,
                                                             C.c_void_p, C.POINTER(C.c_int)]
         _lib.ksw_style_batch.restype = None
+        _lib.ksw_style_batch_stops.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p,
+                                                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        _lib.ksw_style_batch_stops.restype = None
+        _lib.agatha_cells_upto_diag.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.agatha_cells_upto_diag.restype = C.c_int64
         _lib.agatha_traceback_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(Params), C.c_int] + [C.c_void_p] * 6
         _lib.agatha_traceback_batch.restype = None
         for f in (_lib.agatha_ref_seq_ops_as_written, _lib.agatha_seq_ops_product_semantics):
@@ -140,6 +145,26 @@ def ksw_style_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, threads=1):
     lib().ksw_style_batch(qbuf.ctypes.data, tbuf.ctypes.data, *[a.ctypes.data for a in arrs], n, C.byref(params),
                           int(threads), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, C.byref(fb))
     return out[0], out[1], out[2], fb.value
+
+
+def effective_cells_batch(qbuf, tbuf, qoff, toff, qlen, tlen, params, threads=1):
+    """SURVEY.md 8(d) "effective cells": the in-band cells (exact band) on the cell anti-diagonals up to the one each pair's
+    z-drop walk ended on (agatha_kernel.h:297-309,319-322 end the reference's loop there), from the AVX2 port (scalar exact-band
+    model outside its int16 domain).  Returns (per-pair effective cells int64[n], per-pair stop anti-diagonal, (score, qend,
+    tend), n_fallback); a pair that never stops has stop = Q + R - 2 and effective = nominal cells."""
+    n = len(qlen)
+    qbuf = np.ascontiguousarray(qbuf, np.uint8)
+    tbuf = np.ascontiguousarray(tbuf, np.uint8)
+    arrs = [np.ascontiguousarray(a, np.uint32) for a in (qoff, toff, qlen, tlen)]
+    out = np.zeros((4, n), np.int32)
+    fb = C.c_int(0)
+    lib().ksw_style_batch_stops(qbuf.ctypes.data, tbuf.ctypes.data, *[a.ctypes.data for a in arrs], n, C.byref(params),
+                                int(threads), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data,
+                                C.byref(fb))
+    w = int(params.band_width)
+    f = lib().agatha_cells_upto_diag
+    eff = np.fromiter((f(int(q), int(r), w, int(d)) for q, r, d in zip(arrs[2], arrs[3], out[3])), np.int64, n)
+    return eff, out[3], (out[0], out[1], out[2]), fb.value
 
 
 def align_pairs(queries, targets, params, **kw):

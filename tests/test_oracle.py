@@ -178,12 +178,14 @@ def test_int16_kernel_model_equals_oracle(seed):
 
 @pytest.mark.parametrize("margin", [1, 4, 16])
 def test_value_steps_decide_nothing_but_the_running_maximum(margin):
-    """The int16 kernel's value steps (align16_body.inc, FAST) in the lane model: all but a pair's last `margin` steps only
-    track the VALUES of the anti-diagonal maxima, per lane and half, and rely on the calm test (a lower bound of every
-    anti-diagonal maximum within z of the running maximum, inside its zone, inside the pair) to decide nothing but the
-    running maximum; pairs that meet a step they cannot decide, or end without the cell of their maximum, are started
-    over on key steps (kind 2).  Whatever the margin, the results are the oracle's; clean pairs are never started over
-    with a window of 16 key steps; broken pairs (z-drop) are."""
+    """The int16 kernel's value steps (align16_body.inc, FAST) in the lane model: all but a pair's first step and its last
+    `margin` (+ 1/128 of its) steps compute no maxima inside the blocks; they bound the running maximum from above and every
+    anti-diagonal maximum from below by the cells of each block's last row and column (round 4; oracle/agatha_lanes_model.c has the
+    argument), and rely on the calm test (the lower bounds within z of the upper bound, inside their zone, inside the pair) to
+    decide nothing but the running maximum; pairs that meet a step they cannot decide, or end without the cell of their
+    maximum, are started over on key steps (kind 2).  Whatever the margin, the results are the oracle's; clean pairs are never
+    started over with a window of 16 key steps (+ what the pair's own rate of rise asks for: the bound is up to 7 mismatches +
+    7 gap extensions above the maximum and the key steps must see the score rise by more than that); broken pairs (z-drop) are."""
     rng = np.random.default_rng(100 + margin)
     started_over = clean_started_over = 0
     for trial in range(6):

@@ -61,6 +61,61 @@ def time_config(qs, ts, scoring, w, z, combos=((10000, 1),), keep_dir=None):
     return out
 
 
+def time_pipeline(qs, ts, scoring, w, z, kernel_gcups=None, batch=8192, batches=16, combos=((1, False), (2, False), (4, False), (2, True), (4, True))):
+    """The stream / batch manager over a sustained feed (wall time of {host fill, H2D, pack, sort, align, D2H},
+    stream-overlapped; reference gasal_align.cu:144-162,254-266 + test_prog.cpp:273-375): `batches` batches of `batch` pairs --
+    the first 2 * batch pairs of the batch at hand, run over again (AGATHA_AMD_REPEAT) -- through `manual` WITHOUT -p (production
+    mode: nothing printed, no events), 2 storages per host thread, -n 1 / 2 / 4 host threads, host ASCII and host-packed (-k).
+    The loop's seconds come from the CLI itself (AGATHA_AMD_LOOP_STATS; the FASTA parse is not in them).  One more run with -p
+    collects the per-batch kernel times and the pairs taken over after the time-out."""
+    from agatha_amd import shard
+    import numpy as np
+    n_file = min(len(qs), 2 * batch)
+    rep = max(1, (batch * batches) // n_file)
+    d = tempfile.mkdtemp(prefix="agatha_pipe_")
+    ref_fa, query_fa = os.path.join(d, "ref.fasta"), os.path.join(d, "query.fasta")
+    write_fasta(ref_fa, qs[:n_file]); write_fasta(query_fa, ts[:n_file])
+    cells_file = float(shard.nominal_cells(np.array([len(x) for x in qs[:n_file]]), np.array([len(x) for x in ts[:n_file]]), w).sum())
+    # (the reference's parser scans options only up to argc - 4, args_parser.cpp:117: without -p the LAST option before the two
+    #  file names must be one that takes a value, so the flag -k goes first)
+    base = ["-m", str(scoring["m"]), "-x", str(scoring["x"]), "-q", str(scoring["q"]), "-r", str(scoring["r"]),
+            "-s", "3", "-z", str(z), "-w", str(w), "-a", str(batch)]
+    runs = []
+    try:
+        for n_threads, packed in combos:
+            stats = os.path.join(d, "loop.txt")
+            if os.path.exists(stats):
+                os.remove(stats)
+            cmd = [MANUAL] + (["-k"] if packed else []) + base + ["-n", str(n_threads), ref_fa, query_fa]
+            env = dict(os.environ, AGATHA_AMD_REPEAT=str(rep), AGATHA_AMD_LOOP_STATS=stats)
+            t0 = time.time()
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, env=env)
+            wall = time.time() - t0
+            sec, pairs, nb, _ = open(stats).read().split()
+            sec = float(sec)
+            gc = cells_file * rep / sec / 1e9
+            runs.append(dict(host_threads=n_threads, host_packed=packed, storages=2 * n_threads, batches=int(nb), pairs=int(pairs),
+                             loop_s=sec, process_wall_s=wall, end_to_end_gcups=gc,
+                             vs_kernel_only=(gc / kernel_gcups) if kernel_gcups else None))
+        # -p once: per-batch kernel milliseconds + taken-over counts of a sustained run (2 threads, host ASCII)
+        r = run_cli(ref_fa, query_fa, scoring, w, z, batch, 2, d)       # (one pass over the file: 2 batches per thread-pair)
+        taken = r["pairs_taken_over"]
+        kms = r["kernel_ms_per_batch"]
+    finally:
+        for f in os.listdir(d):
+            os.remove(os.path.join(d, f))
+        os.rmdir(d)
+    best = max(runs, key=lambda x: x["end_to_end_gcups"])
+    best_k = max((x for x in runs if x["host_packed"]), key=lambda x: x["end_to_end_gcups"], default=None)
+    # the share of the H2D copies that is hidden: per batch the stream carries copy + kernels; what the loop takes per batch
+    # beyond the kernel time is what was not hidden (negative: the batches overlap on the GPU)
+    return dict(protocol="agatha_amd/manual (no -p), AGATHA_AMD_REPEAT: %d batches of %d pairs through gasal_aln_async, 2 storages per host thread; "
+                         "seconds of the batch loop (host fill + H2D + pack + sort + align + D2H, overlapped)" % (batches, batch),
+                runs=runs, best_end_to_end_gcups=best["end_to_end_gcups"], best_config={k: best[k] for k in ("host_threads", "host_packed")},
+                best_host_packed_vs_kernel_only=(best_k["vs_kernel_only"] if best_k else None),
+                kernel_ms_per_batch_with_p=kms, pairs_taken_over_with_p=taken)
+
+
 if __name__ == "__main__":
     from agatha_amd import workload
     name = sys.argv[1] if len(sys.argv) > 1 else "C1"
