@@ -325,7 +325,9 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.mig_test_delay_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TEST_DELAY_US), 0);
     L.fast_margin = std::max(opt(OPT_FAST_MARGIN), 0);
     L.ck_buf = have_ck ? (uint32_t*)((char*)d_workspace + ck_off) : nullptr;
-    L.ck_slots = 1 << 30;           // (the area is sized for every lane group any shape's grid can have for this many pairs)
+    // (what the caller's workspace really holds behind ck_off: the kernel derives from it how many of ITS lane groups fit -- a grid
+    //  made larger than the default with the max_blocks debug option must not write checkpoints past the end of the workspace)
+    L.ck_dwords = have_ck ? (unsigned long long)((workspace_bytes - ck_off) / sizeof(uint32_t)) : 0ull;
     L.ck_min_steps = opt(OPT_CK_MIN_STEPS);
     L.static_ck = opt(OPT_STATIC_CK) ? 1 : 0;
     L.fast_anchor = opt(OPT_FAST_ANCHOR) ? 1 : 0;

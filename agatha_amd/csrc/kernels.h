@@ -54,7 +54,7 @@ struct AlignLaunch {
     unsigned int mig_test_delay_ticks;   // tests: odd lane groups sleep this long before they start (forces the take-over)
     unsigned int* step_stats;      // device: [0] value wave-steps, [1] key wave-steps, [2] pairs started over, [3] pairs started (int16 kernel)
     uint32_t* ck_buf;              // device: checkpoints of the int16 kernel's long pairs, two slots of a suspended pair's size per lane group (nullptr: none)
-    int ck_slots;                  // lane groups the area has room for
+    unsigned long long ck_dwords;  // dwords of that area; a kernel shape <G, P> has room for ck_dwords / (2 * mig_fields(P) * G) lane groups in it
     int ck_min_steps;              // pairs of fewer steps take no checkpoints
     int fast_anchor;               // 1: the window of key steps starts before the corner of the shorter sequence (default); 0: before the pair's last step (experiments)
     int static_ck;                 // on a static schedule the three-register-pair shapes: 1 = checkpoints and going back to them in place, 0 = none, a pair that must start over goes to the int32 kernel

@@ -553,7 +553,9 @@ int gasal_is_aln_async_done(gasal_gpu_storage_t* s)
         //  line "n_alns kernel_ms value_steps key_steps started_over went_back_to_checkpoint taken_over" there --
         //  agatha_amd_step_stats; taken_over counts the pairs a lane group took from a neighbour that did not show up in time)
         static const char* stats_path = getenv("AGATHA_AMD_RAW_STATS");
-        if (stats_path && *stats_path) {
+        // (not with start positions: agatha_amd_align_starts has by now run the batch again, backwards, on the same workspace, and the
+        //  counters would be that pass's, not the timed kernel's)
+        if (stats_path && *stats_path && !(p && p->start_pos)) {
             unsigned int st[40] = {0};
             if (agatha_amd_step_stats(s->str, s->workspace, s->timing_n_alns, st) == 0) {
                 std::lock_guard<std::mutex> lock(g_raw_mutex);
