@@ -347,21 +347,109 @@ int key_bits_for_window(int window_blocks)
 // Writes the launch record, resets the queue heads and picks the kernel for the plain pairs: the candidate with the
 // smallest max(longest pair alone, whole batch spread over the candidate's lane groups).  A batch with a few very
 // long pairs is bound by their latency (fewer blocks per lane and step win), a uniform one by throughput.
-__global__ void record_kernel(AlignLaunch L, AlignLaunch* rec)
+// Round 4, a batch of mixed lengths (BASELINE configs[4]; the purpose of the reference's uneven bucketing, agatha_kernel.h:113,
+// and subwarp rejoining, :365-408, re-derived): ONE shape per launch made 19 000 short pairs run on the latency shape because a
+// few hundred were long, or the long ones crawl on the throughput shape.  When both int16 shapes are candidates the batch may
+// be SPLIT by length: the sorted order's first `n_long` pairs go to the latency shape (candidate 1, launched on a second
+// stream, one pair per wave), the rest to the throughput shape (candidate 0) on its work queue, side by side on the chip.  The
+// threshold is the bucket of the length histogram that minimises
+//     max(longest * t_lat(latency shape), longest short pair * t_load(throughput shape),
+//         (steps of the short pairs * t_load(thr) + steps of the long pairs * t_load(lat) * lane groups a wave displaces) / lane groups)
+// over all 16 384 buckets (256 threads, 64 buckets each, a suffix scan over the threads); it is taken when that beats the best single
+// shape by 7 %.  queue[11] = n_long (0: no split); the static schedule is switched off with it.
+__global__ void __launch_bounds__(256)
+record_kernel(AlignLaunch L, AlignLaunch* rec, const uint32_t* __restrict__ hist, uint32_t nbuckets, int allow_split)
 {
-    *rec = L; L.queue[0] = 0u; L.queue[1] = 0u; L.queue[2] = 0u; L.queue[3] = 0u;
+    __shared__ float s_steps[256];
+    __shared__ float s_cost[256];
+    __shared__ uint32_t s_bucket[256];
+    const int t = threadIdx.x;
     const float total = L.totals[0], longest = L.totals[1];
     int best = 0; float bestc = 3.4e38f;
     for (int c = 0; c < L.ncand; c++) {
-        const float cost = fmaxf(longest * L.cand[c].t_lat, total * L.cand[c].t_load / (float)L.cand[c].capacity);
+        // (the longest pair alone: on a shape with several pairs per wave it never is -- its wave's other lane groups keep drawing
+        //  pairs --, so it advances at the loaded step time there unless it is the whole batch)
+        const float tl = (L.cand[c].G < 64 && L.n > L.cand[c].capacity / 2) ? L.cand[c].t_load : L.cand[c].t_lat;
+        const float cost = fmaxf(longest * tl, total * L.cand[c].t_load / (float)L.cand[c].capacity);
         if (cost < bestc) { bestc = cost; best = c; }
     }
-    *L.choice = (L.force_choice >= 0 && L.force_choice < L.ncand) ? L.force_choice : best;
+    const bool can_split = allow_split && hist != nullptr && L.ncand >= 2 && L.cand[0].kind == 1 && L.cand[1].kind == 1 && L.cand[0].G < 64 &&
+                           L.force_choice < 0 && L.n > 64;
+    uint32_t n_long = 0;
+    if (can_split) {          // (uniform: every thread takes the branch or none)
+        const uint32_t per = (nbuckets + 255u) / 256u;
+        // thread t owns the buckets [t * per, (t + 1) * per); after the scatter hist[b] = pairs in buckets >= b
+        const uint32_t b0 = (uint32_t)t * per, b1 = min(b0 + per, nbuckets);
+        float mine = 0.f;
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t c = hist[b] - (b + 1 < nbuckets ? hist[b + 1] : 0u);
+            mine += (float)c * (4.f * (float)b + 2.f);
+        }
+        s_steps[t] = mine;
+        __syncthreads();
+        if (t == 0) { float acc = 0.f; for (int j = 255; j >= 0; j--) { const float v = s_steps[j]; s_steps[j] = acc; acc += v; } }   // steps in the buckets ABOVE thread j's
+        __syncthreads();
+        const KernelChoice &A = L.cand[1], &B = L.cand[0];
+        const float rf = (float)A.G / (float)B.G, capB = (float)B.capacity;
+        float above = s_steps[t];                       // steps of the pairs in buckets > b (walking down from b1 - 1)
+        float bc = 3.4e38f; uint32_t bb = 0;
+        for (uint32_t b = b1; b-- > b0;) {
+            // threshold: buckets >= b + 1 are long (steps `above`), bucket b holds the longest short pair
+            const uint32_t cnt = hist[b] - (b + 1 < nbuckets ? hist[b + 1] : 0u);
+            const uint32_t nl = b + 1 < nbuckets ? hist[b + 1] : 0u;
+            // (every split has one bucket that holds its longest short pair: only those are looked at)
+            // ... and the long pairs must leave the chip to the others: a pair on the latency shape holds a whole wave slot for its
+            // life, and the throughput shape's workgroups cannot start on a CU whose slots are taken (C4 at 20 000 pairs with a quarter
+            // of the steps on 1 900 waves: 204 ms against 161 on the latency shape alone)
+            if (cnt > 0u && nl > 0u && nl < (uint32_t)L.n && 4u * nl <= (uint32_t)A.capacity) {
+                const float lshort = 4.f * (float)b + 2.f;
+                const float c = fmaxf(fmaxf(longest * A.t_lat, lshort * B.t_load), ((total - above) * B.t_load + above * A.t_load * rf) / capB);
+                if (c < bc) { bc = c; bb = b + 1; }
+            }
+            above += (float)cnt * (4.f * (float)b + 2.f);
+        }
+        s_cost[t] = bc; s_bucket[t] = bb;
+        __syncthreads();
+        if (t == 0) {
+            float c = 3.4e38f; uint32_t b = 0;
+            for (int j = 0; j < 256; j++) if (s_cost[j] < c) { c = s_cost[j]; b = s_bucket[j]; }
+            if (c < 0.93f * bestc && b > 0u && b < nbuckets) n_long = hist[b];
+        }
+    }
+    if (t == 0) {
+        *rec = L; L.queue[0] = 0u; L.queue[1] = 0u; L.queue[2] = 0u; L.queue[3] = 0u; L.queue[4] = 0u; L.queue[5] = 0u; L.queue[6] = 0u; L.queue[7] = 0u;
+        L.queue[11] = n_long;
+        if (n_long) { best = 0; L.sched[0] = 0; }
+        *L.choice = (L.force_choice >= 0 && L.force_choice < L.ncand) ? L.force_choice : best;
+    }
 }
 
-hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st)
+// A batch split by length: the throughput shape's 512 workgroups fill every CU (two of them take 159 of its 160 KB of LDS), and a
+// workgroup of the latency shape that is dispatched a microsecond later finds no room until one of them ends -- the 64 long pairs
+// of a 40 000-pair batch then ran in four rounds on the handful of workgroups that had got in, 157 ms instead of 65.  So the
+// throughput shape's launch waits, on its own stream, behind this one-wave kernel: until every long pair has been drawn by a
+// resident wave of the latency shape (queue[5] counts them), or 300 us have passed.
+__global__ void split_gate_kernel(AlignLaunch L)
 {
-    hipLaunchKernelGGL(record_kernel, dim3(1), dim3(1), 0, st, L, rec);
+    const unsigned int n_long = L.queue[11];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (n_long == 0u) {
+        // No split.  If the throughput shape takes the batch, its grid -- every workgroup resident, two per CU, the static schedule
+        // counts on it -- must not be dispatched among the latency shape's workgroups that are still on their way out (measured: one
+        // launch in two took 30.4 instead of 26.2 ms): wait for the last of them (queue[7]), at most 100 us.
+        if (*L.choice != 0) return;
+        while (__hip_atomic_load(L.queue + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && __builtin_amdgcn_s_memrealtime() - t0 < 10000ull)
+            __builtin_amdgcn_s_sleep(8);
+        return;
+    }
+    while (__hip_atomic_load(L.queue + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_long &&
+           __builtin_amdgcn_s_memrealtime() - t0 < 30000ull)
+        __builtin_amdgcn_s_sleep(32);
+}
+
+hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st, const uint32_t* hist, uint32_t nbuckets, int allow_split)
+{
+    hipLaunchKernelGGL(record_kernel, dim3(1), dim3(256), 0, st, L, rec, hist, nbuckets, allow_split);
     return hipGetLastError();
 }
 
@@ -414,7 +502,9 @@ schedule_kernel(AlignLaunch L, int GS, int G)
         // which short pairs (a bundled-dataset-like batch: 750 steps each) pay for more than they gain (24.7 against 21.1 ms);
         // beyond that the queue balances by itself (70 000 pairs: 223.7 against 227.2 ms) and also follows pairs that z-drop early.
         const long long pavg = npairs ? P / (long long)npairs : 0;
-        const bool use = pm > 0 && P < (1ll << 30) && (L.mig_enabled == 2 || 10ll * n <= 22ll * m || pavg >= 12ll * (W + 1));
+        // ... and not when the longest pair is several times the average one (a batch of mixed lengths: T is then that pair, most lane
+        // groups stand idle for most of it, and a pair that z-drops early frees nobody: C4 at 20 000 pairs 378 ms against 160)
+        const bool use = pm > 0 && P < (1ll << 30) && (L.mig_enabled == 2 || ((10ll * n <= 22ll * m || pavg >= 12ll * (W + 1)) && (long long)pm <= 3ll * pavg));
         L.sched[0] = use ? 1 : 0; L.sched[1] = use ? (int)T : 0; L.sched[2] = use ? (int)((P + T - 1) / T) : 0;
     }
     __syncthreads();
@@ -479,12 +569,14 @@ hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool fo
         k.kind = 1; k.G = G16; k.S = 2 * P16;
         // (microseconds per step, round 2: a lone wave 7.2 / 6.7 / 3.6 for P = 3 / 2 / 1; two waves per SIMD taking turns at
         //  the issue priority 10.3 / 7.8 / ~5)
-        k.t_lat = 1.8f * P16 + 1.8f; k.t_load = 2.55f * P16 + 2.6f;
+        // (round 4, value steps without maxima inside the block: a lone wave 2.6 / 5.6 for P = 1 / 3, two waves per SIMD 3.3 / 6.4 / 8.3
+        //  for P = 1 / 2 / 3: profiles/r04_v1/other_configs.txt)
+        k.t_lat = 1.5f * P16 + 1.1f; k.t_load = 2.45f * P16 + 1.0f;
         k.capacity = L.num_cus * 8 * (64 / G16);
         L.cand[L.ncand++] = k;
         if (GL16 && !force16) {
             k.G = GL16; k.S = 2 * PL16;
-            k.t_lat = 1.8f * PL16 + 1.8f + (GL16 == 128 ? 0.4f : 0.f); k.t_load = 2.55f * PL16 + 2.6f;
+            k.t_lat = 1.5f * PL16 + 1.1f + (GL16 == 128 ? 0.6f : 0.f); k.t_load = 2.45f * PL16 + 1.0f;
             k.capacity = GL16 == 128 ? L.num_cus * 4 : L.num_cus * 8 * (64 / GL16);
             L.cand[L.ncand++] = k;
         }
@@ -496,7 +588,8 @@ hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool fo
     return hipSuccess;
 }
 
-hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st)
+hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st, hipStream_t aux, hipEvent_t fork,
+                        hipEvent_t join)
 {
     const Cfg *thr, *lat;
     pick_shapes(window_blocks, &thr, &lat);
@@ -508,13 +601,28 @@ hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int
     // (after the int16 kernel, which produces them) even when it is not a candidate
     int kid_thr = -2;
     hipError_t e = hipSuccess;
+    // The int16 latency shape (candidate 1 behind an int16 candidate 0) goes to the second stream, FIRST, so that a batch split by
+    // length has its long pairs on the chip before the throughput shape's workgroups fill it; the first stream waits for it behind
+    // its own int16 kernel.  (When the device chose one shape, the other returns at once wherever it was launched.)
+    const bool two_streams = aux != nullptr && fork != nullptr && join != nullptr && L.ncand >= 2 && L.cand[0].kind == 1 && L.cand[1].kind == 1;
+    if (two_streams) {
+        e = hipEventRecord(fork, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(aux, fork, 0);
+        if (e == hipSuccess) e = launch_align16(L, L.cand[1].G, L.cand[1].S / 2, 1, aux);
+        if (e == hipSuccess) e = hipEventRecord(join, aux);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(split_gate_kernel, dim3(1), dim3(64), 0, st, L);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     for (int c = 0; c < L.ncand && e == hipSuccess; c++) {
         const KernelChoice& k = L.cand[c];
-        if (k.kind == 1) e = launch_align16(L, k.G, k.S / 2, c, st);
+        if (k.kind == 1) { if (!(two_streams && c == 1)) e = launch_align16(L, k.G, k.S / 2, c, st); }
         else if (k.G == thr->G && k.S == thr->S) kid_thr = c;
         else if (lat) e = lat->fn(L, 0, c, st);
     }
     if (e != hipSuccess) return e;
+    if (two_streams) { e = hipStreamWaitEvent(st, join, 0); if (e != hipSuccess) return e; }
     e = thr->fn(L, 1, kid_thr, st);
     if (e != hipSuccess) return e;
     return thr->fn(L, 2, -1, st);          // compare kernel: walks the queue only if pairs with other letters exist

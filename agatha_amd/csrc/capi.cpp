@@ -39,12 +39,14 @@ DebugOption g_opts[] = {
     {"prio_slice", "AGATHA_AMD_PRIO_SLICE", {-1}},     // > 0: SIMD partners alternate issue priority every 2^n ticks (10 ns each); -1: 2^15 on a static schedule, off otherwise; 0: off
     {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts); -1: also no priority by the length of a wave's pair on the latency shapes' work queue
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
+    {"no_split", "AGATHA_AMD_NO_SPLIT", {0}},          // 1: a batch of mixed lengths is never split between the two int16 shapes (one shape per launch, as before round 4)
+    {"prio_fine", "AGATHA_AMD_PRIO_FINE", {0}},        // quarters of a slice added to slot 0's share of the issue priority (static schedule)
     {"fast_margin", "AGATHA_AMD_FAST_MARGIN", {12}},   // int16 kernel: value steps except in a window of key steps at a pair's end that starts n + steps / 128 before the corner of the shorter sequence; 0: key steps only
     {"fast_anchor", "AGATHA_AMD_FAST_ANCHOR", {1}},   // int16 kernel: 1 = the window of key steps is anchored at the corner of the shorter sequence, 0 = at the pair's last step (experiments)
     {"static_ck", "AGATHA_AMD_STATIC_CK", {1}},   // int16 kernel, static schedule, three register pairs per lane: 1 = checkpoints there as well (a pair that must be started over goes back in place), 0 = none (such a pair goes to the int32 kernel behind)
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {1024}},   // int16 kernel: pairs of at least this many steps take checkpoints (0: none do)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_CK_MIN_STEPS, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -71,6 +73,27 @@ int num_cus()
     return cached;
 }
 
+// A second stream per (host thread, device) for the latency shape of a batch that the device splits by length between the two
+// packed-int16 shapes (record_kernel), with the two events of the fork and the join.  Created on first use, kept for the
+// life of the thread (a handful per process: one per host thread that calls agatha_amd_align, per GPU it uses).
+struct AuxStream { int dev; hipStream_t s; hipEvent_t fork, join; };
+AuxStream* aux_stream()
+{
+    static thread_local AuxStream cache[16];
+    static thread_local int used = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (int k = 0; k < used; k++) if (cache[k].dev == dev) return &cache[k];
+    if (used == 16) return nullptr;
+    AuxStream a; a.dev = dev;
+    if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); return nullptr;
+    }
+    cache[used] = a;
+    return &cache[used++];
+}
+
 // Batches of more pairs than this can be larger than one round of the packed-int16 kernel's lane groups: their workspace
 // also holds the areas of the preemptive schedule (prefix sums, boundary states, suspended pair state: ~68 MiB).
 constexpr uint32_t kMigMinPairs = 4096;
@@ -95,13 +118,16 @@ size_t ck_groups(int G, uint32_t n)
     const size_t groups = G == 128 ? cus * 4 : cus * 8 * (size_t)(64 / G);
     return std::min<size_t>(groups, (size_t)n + 16);       // (a grid of whole workgroups: up to 16 lane groups each)
 }
-size_t ck_workspace_bytes(uint32_t n)
+// (two parts: the shapes with fewer than 64 lanes per pair, then the ones with 64 and more -- a batch split by length between a
+//  throughput and a latency shape runs both at the same time)
+size_t ck_part_bytes(uint32_t n, bool lat)
 {
     size_t need = 0;
     for (const CkShape& s : kCkShapes)
-        need = std::max(need, ck_groups(s.G, n) * 2 * (size_t)agatha::align16_mig_fields(s.P) * (size_t)s.G * sizeof(uint32_t));
+        if ((s.G >= 64) == lat) need = std::max(need, ck_groups(s.G, n) * 2 * (size_t)agatha::align16_mig_fields(s.P) * (size_t)s.G * sizeof(uint32_t));
     return round_up(need);
 }
+size_t ck_workspace_bytes(uint32_t n) { return ck_part_bytes(n, false) + ck_part_bytes(n, true); }
 
 }  // namespace
 
@@ -317,6 +343,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     HIPCHK(hipMemsetAsync(simd_steps, 0, sizeof(int) * agatha::kSimdStepsInts, st));
     L.prio_slice_bits = opt(OPT_PRIO_SLICE);
     L.prio_duty = opt(OPT_PRIO_DUTY);
+    L.prio_fine = opt(OPT_PRIO_FINE);
     if (opt(OPT_TIMELINE) && workspace_bytes >= base_workspace_bytes(n_alns) + mig_workspace_bytes(n_alns)) {
         L.timeline = timeline;
         HIPCHK(hipMemsetAsync(timeline, 0, sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords, st));
@@ -328,6 +355,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     // (what the caller's workspace really holds behind ck_off: the kernel derives from it how many of ITS lane groups fit -- a grid
     //  made larger than the default with the max_blocks debug option must not write checkpoints past the end of the workspace)
     L.ck_dwords = have_ck ? (unsigned long long)((workspace_bytes - ck_off) / sizeof(uint32_t)) : 0ull;
+    L.ck_lat_off = (unsigned long long)(ck_part_bytes(n_alns, false) / sizeof(uint32_t));
     L.ck_min_steps = opt(OPT_CK_MIN_STEPS);
     L.static_ck = opt(OPT_STATIC_CK) ? 1 : 0;
     L.fast_anchor = opt(OPT_FAST_ANCHOR) ? 1 : 0;
@@ -350,7 +378,9 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         }
     }
     L.self_dev = rec;
-    HIPCHK(agatha::launch_record(L, rec, st));     // device copy of the record, queue head reset, kernel choice; stream-ordered
+    // device copy of the record, queue head reset, kernel choice (one shape, or the batch split by length between the two int16
+    // shapes: debug option no_split); stream-ordered
+    HIPCHK(agatha::launch_record(L, rec, st, hist, kBuckets, (!tb && opt(OPT_NO_SPLIT) == 0) ? 1 : 0));
     if (tb) {
         // the pairs with plain letters run on the int16 kernel where a shape with the pass's slot count exists (bands of 49..192
         // blocks), the int32 kernel behind it takes the rest of the pass: other letters, N in the query, pairs it abandoned
@@ -364,7 +394,8 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         return 0;
     }
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));
-    HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st));
+    AuxStream* ax = (opt(OPT_NO_SPLIT) == 0) ? aux_stream() : nullptr;
+    HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st, ax ? ax->s : nullptr, ax ? ax->fork : nullptr, ax ? ax->join : nullptr));
     if (g_ev1) HIPCHK(hipEventRecord(g_ev1, st));
     return 0;
 }
@@ -496,6 +527,22 @@ int agatha_amd_kernel_choice(void* stream, const void* d_workspace, uint32_t n_a
     if (e != hipSuccess) return hip_fail(e, "agatha_amd_kernel_choice");
     if (choice < 0 || choice >= rec.ncand) return AGATHA_AMD_EINVAL;
     out[0] = rec.cand[choice].kind; out[1] = rec.cand[choice].G; out[2] = rec.cand[choice].S;
+    return 0;
+}
+
+int agatha_amd_split_info(void* stream, const void* d_workspace, uint32_t n_alns, int out[3])
+{
+    if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
+    const char* ws = (const char*)d_workspace;
+    ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets);
+    unsigned int n_long = 0;
+    agatha::AlignLaunch rec;
+    hipError_t e = hipMemcpyAsync(&n_long, ws + 11 * sizeof(unsigned int), sizeof(n_long), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&rec, ws + kAlign, sizeof(rec), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "agatha_amd_split_info");
+    out[0] = (int)n_long; out[1] = out[2] = 0;
+    if (n_long && rec.ncand >= 2) { out[1] = rec.cand[1].G; out[2] = rec.cand[1].S; }
     return 0;
 }
 

@@ -51,10 +51,13 @@ struct AlignLaunch {
     int prio_slice_bits;           // > 0: the two waves of a SIMD take turns at high issue priority, in slices of 2^bits ticks of the 100 MHz clock
     int* simd_steps;               // device: [2 workgroups][CU][SIMD] step counts the waves of a dealt single round tell each other
     int prio_duty;                 // of every 16 slices, the wave in slot 0 of its SIMD is the favoured one in this many
+    int prio_fine;                 // ... plus this many quarters of a slice (debug option prio_fine: the arbiter is not quite even-handed)
     unsigned int mig_test_delay_ticks;   // tests: odd lane groups sleep this long before they start (forces the take-over)
     unsigned int* step_stats;      // device: [0] value wave-steps, [1] key wave-steps, [2] pairs started over, [3] pairs started (int16 kernel)
     uint32_t* ck_buf;              // device: checkpoints of the int16 kernel's long pairs, two slots of a suspended pair's size per lane group (nullptr: none)
-    unsigned long long ck_dwords;  // dwords of that area; a kernel shape <G, P> has room for ck_dwords / (2 * mig_fields(P) * G) lane groups in it
+    unsigned long long ck_dwords;  // dwords of that area ...
+    unsigned long long ck_lat_off; // ... of which the first ck_lat_off belong to the shapes with fewer than 64 lanes per pair, the rest to the others (a batch split by
+                                   // length runs one of each at the same time); a shape <G, P> has room for (its part) / (2 * mig_fields(P) * G) lane groups
     int ck_min_steps;              // pairs of fewer steps take no checkpoints
     int fast_anchor;               // 1: the window of key steps starts before the corner of the shorter sequence (default); 0: before the pair's last step (experiments)
     int static_ck;                 // on a static schedule the three-register-pair shapes: 1 = checkpoints and going back to them in place, 0 = none, a pair that must start over goes to the int32 kernel
@@ -93,7 +96,10 @@ constexpr size_t kMigBufBytes = (size_t)68 << 20;
 // usable and not disabled, int32 throughput shape = smallest (G, S) covering the window, int32 latency shape = 64 lanes
 // per pair with fewer slots); launch_align launches them (+ the compare kernel) in that order.
 hipError_t plan_align(AlignLaunch& L, int window_blocks, bool disable16, bool force16);
-hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st);
+// (aux: a second stream for the latency shape of the packed-int16 kernel, so that a batch split by length runs its two shapes
+//  side by side; fork / join: two events the caller owns; nullptr: everything on st)
+hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int* S_out, hipStream_t st, hipStream_t aux = nullptr,
+                        hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 int max_window_blocks();
 // packed-int16 kernel (align16_kernel.hip): the (G, P) of its throughput shape for this window and, if there is one with
 // fewer blocks per lane, of its latency shape (64 lanes per pair; *GL = 0 if none); and its launcher
@@ -107,7 +113,9 @@ hipError_t launch_align16_tb(const AlignLaunch& L, int G, int P, int pass, hipSt
 int key_bits_for_window(int window_blocks);
 // writes L into *rec on the device (by-value kernel argument: no host-memory lifetime to care about) and zeroes *L.queue
 hipError_t launch_exotic(const AlignLaunch& L, hipStream_t st);
-hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st);
+// (hist: the sort's cumulative length histogram, for the split of a mixed batch between the two int16 shapes; nullptr / 0: none)
+hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st, const uint32_t* hist = nullptr, uint32_t nbuckets = 0,
+                         int allow_split = 0);
 // step counts, their prefix sums and the decision static / dynamic (after launch_sort and launch_exotic)
 hipError_t launch_schedule(const AlignLaunch& L, hipStream_t st);
 // dwords of suspended state per lane of the packed-int16 kernel <G, P>

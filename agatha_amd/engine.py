@@ -94,6 +94,7 @@ def load_library():
     lib.agatha_amd_kernel_choice.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
     lib.agatha_amd_timeline.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.agatha_amd_schedule_info.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
+    lib.agatha_amd_split_info.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
     lib.agatha_amd_step_stats.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint)]
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.agatha_amd_free.argtypes = [vp]
@@ -118,7 +119,7 @@ EXPORTS = [
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_workspace_bytes_long", "agatha_amd_pack", "agatha_amd_pack_host",
     "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_starts_scratch_bytes", "agatha_amd_align_starts", "agatha_amd_traceback_pair_bytes",
     "agatha_amd_traceback_scratch_bytes",
-    "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_step_stats", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_split_info", "agatha_amd_step_stats", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -356,6 +357,15 @@ class DeviceBatch:
         c = (C.c_int * 3)()
         _chk(lib, lib.agatha_amd_schedule_info(st, self.d_ws.ptr, self.n, c))
         return bool(c[0]), int(c[1]), int(c[2])
+
+    def split_info(self, stream=None):
+        """(pairs that ran on the int16 latency shape beside the throughput shape, its lanes per pair, its slots per lane) of the last
+        align(): see agatha_amd_split_info; (0, 0, 0) when one shape took the batch."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        c = (C.c_int * 3)()
+        _chk(lib, lib.agatha_amd_split_info(st, self.d_ws.ptr, self.n, c))
+        return int(c[0]), int(c[1]), int(c[2])
 
     def step_stats(self, stream=None):
         """(value wave-steps, key wave-steps, pairs started over, pairs started) of the int16 kernel in the last align()."""

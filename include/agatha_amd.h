@@ -66,7 +66,7 @@ int agatha_amd_max_band(void);
 size_t agatha_amd_workspace_bytes(uint32_t max_n_alns);
 /* The same plus, when the sequences can be long (ceil(query / 8) + ceil(target / 8) >= 1024 -- the debug option ck_min_steps --, or a length given as 0 =
  * unknown), the checkpoint area of the packed-int16 kernel: two slots of ~8-58 KiB per lane group in flight (at most
- * ~130 MiB), where a long pair's state is saved every eighth of its steps.  A long pair that must be started over -- z-drop
+ * ~200 MiB), where a long pair's state is saved every eighth of its steps.  A long pair that must be started over -- z-drop
  * came into reach on a step that only tracked the maxima's values -- then goes back one checkpoint instead of to its first
  * step.  A caller that passes the smaller size gets the same results, only slower on such pairs. */
 size_t agatha_amd_workspace_bytes_long(uint32_t max_n_alns, uint32_t max_query_len, uint32_t max_target_len);
@@ -200,6 +200,13 @@ int agatha_amd_get_debug_option(const char* name, int* value);
  * the batch's length histogram -- latency of the longest pair against throughput over the whole batch.)  Synchronises
  * the stream. */
 int agatha_amd_kernel_choice(void* stream, const void* d_workspace, uint32_t n_alns, int out[3]);
+
+/* Diagnostics: a batch of mixed lengths may be split between the two shapes of the packed-int16 kernel (round 4; the purpose of
+ * the reference's uneven bucketing and subwarp rejoining, agatha_kernel.h:113 / :365-408, re-derived): out[0] = the number of pairs
+ * -- the longest ones -- that ran on the latency shape, side by side with the rest on the throughput shape agatha_amd_kernel_choice
+ * reports (0: one shape took them all); out[1], out[2] = lanes per pair and slots per lane of that latency shape.  Debug option
+ * "no_split" = 1 switches the split off.  Synchronises the stream. */
+int agatha_amd_split_info(void* stream, const void* d_workspace, uint32_t n_alns, int out[3]);
 
 /* Diagnostics: the preemptive schedule of the last agatha_amd_align() on this workspace.  out[0] = 1 if the packed-int16
  * throughput kernel ran the batch on a static schedule in which pairs move between lane groups (more pairs than lane

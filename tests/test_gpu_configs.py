@@ -203,3 +203,44 @@ def test_c1_with_broken_pairs_on_the_static_schedule(eng):
     _sampled_check((qs, ts), got, np.sort(np.concatenate([broken, others])), p)
     ql, tl = batch[4].astype(np.int64), batch[5].astype(np.int64)
     assert np.mean((got[1] + got[2] + 2 < 0.95 * (ql + tl))[broken]) > 0.7          # they did end early
+
+
+def test_a_few_long_pairs_among_many_short_ones_are_split_between_the_two_int16_shapes(eng):
+    """Round 4 (the purpose of the reference's uneven bucketing, agatha_kernel.h:113, and subwarp rejoining, :365-408, re-derived
+    for a batch of mixed lengths): 20 000 bundled-dataset-like pairs with 12 pairs of 30 kb among them.  One shape per launch puts
+    everything on the latency shape (the short pairs at 60 % of the throughput shape's rate) or makes the long pairs crawl on the
+    throughput shape; the device now sends the long ones to <64, 1>, one pair per wave on a second stream, and the rest to <16, 3>,
+    side by side.  Asserted: both shapes ran (agatha_amd_split_info), every long pair and 1 500 short ones spread over the batch
+    equal the oracle, the whole batch equals a run with the split switched off."""
+    import agatha_amd
+    qs, ts = synth.cfg_c0(n=20000)
+    lq, lt = synth.make_pairs(77, 12, lambda r: int(r.integers(29000, 31000)), 0.03, 0.03, 0.04)
+    pos = np.sort(np.random.default_rng(3).choice(20000, 12, replace=False))
+    for k, at in enumerate(pos):
+        qs.insert(int(at) + k, lq[k]); ts.insert(int(at) + k, lt[k])
+    where_long = [int(at) + k for k, at in enumerate(pos)]
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
+        got = [b.res_host[j].copy() for j in range(3)]
+        choice, split, st = b.kernel_choice(), b.split_info(), b.step_stats()
+        agatha_amd.set_debug_option("no_split", 1)
+        try:
+            b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
+            one_shape = [b.res_host[j].copy() for j in range(3)]
+            assert b.split_info()[0] == 0
+        finally:
+            agatha_amd.set_debug_option("no_split", 0)
+    finally:
+        b.free()
+    # the throughput shape + the 12 long pairs (and whichever of the longest short ones the cost model sends along) on <64, 1>
+    assert choice == ("int16", 16, 6) and 12 <= split[0] <= 512 and split[1:] == (64, 2), (choice, split)
+    assert all((a == c).all() for a, c in zip(got, one_shape))
+    k = np.unique(np.concatenate([np.asarray(where_long), np.random.default_rng(4).choice(len(qs), 1500, replace=False)]))
+    sb = O.make_batch([qs[i] for i in k]), O.make_batch([ts[i] for i in k])
+    exp = O.align_batch(sb[0][0], sb[1][0], sb[0][1], sb[1][1], sb[0][2], sb[1][2], O.make_params(**p), wide=True,
+                        model=O.MODEL_SLICES, threads=16)
+    assert all((np.asarray(a)[k] == e).all() for a, e in zip(got, exp))
