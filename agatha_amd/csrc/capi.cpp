@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -73,25 +75,32 @@ int num_cus()
     return cached;
 }
 
-// A second stream per (host thread, device) for the latency shape of a batch that the device splits by length between the two
-// packed-int16 shapes (record_kernel), with the two events of the fork and the join.  Created on first use, kept for the
-// life of the thread (a handful per process: one per host thread that calls agatha_amd_align, per GPU it uses).
-struct AuxStream { int dev; hipStream_t s; hipEvent_t fork, join; };
-AuxStream* aux_stream()
+// A second stream beside every stream agatha_amd_align is called on, for the latency shape of a batch that the device splits by
+// length between the two packed-int16 shapes (record_kernel), with the two events of the fork and the join.  Streams made by
+// agatha_amd_stream_create get theirs there (the GASAL layer's: nothing is created inside a timed batch); a foreign stream
+// (torch's, the null stream) gets one at its first call.  Kept until agatha_amd_stream_destroy / for the life of the process.
+struct AuxStream { hipStream_t s; hipEvent_t fork, join; };
+std::mutex g_aux_mutex;
+std::unordered_map<void*, AuxStream> g_aux;
+AuxStream* aux_stream(void* main_stream)
 {
-    static thread_local AuxStream cache[16];
-    static thread_local int used = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    for (int k = 0; k < used; k++) if (cache[k].dev == dev) return &cache[k];
-    if (used == 16) return nullptr;
-    AuxStream a; a.dev = dev;
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    auto it = g_aux.find(main_stream);
+    if (it != g_aux.end()) return &it->second;
+    AuxStream a;
     if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError(); return nullptr;
     }
-    cache[used] = a;
-    return &cache[used++];
+    return &g_aux.emplace(main_stream, a).first->second;
+}
+void aux_stream_drop(void* main_stream)
+{
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    auto it = g_aux.find(main_stream);
+    if (it == g_aux.end()) return;
+    (void)hipStreamDestroy(it->second.s); (void)hipEventDestroy(it->second.fork); (void)hipEventDestroy(it->second.join);
+    g_aux.erase(it);
 }
 
 // Batches of more pairs than this can be larger than one round of the packed-int16 kernel's lane groups: their workspace
@@ -394,7 +403,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         return 0;
     }
     if (g_ev0) HIPCHK(hipEventRecord(g_ev0, st));
-    AuxStream* ax = (opt(OPT_NO_SPLIT) == 0) ? aux_stream() : nullptr;
+    AuxStream* ax = (opt(OPT_NO_SPLIT) == 0) ? aux_stream(stream) : nullptr;
     HIPCHK(agatha::launch_align(L, (int)window, &g_lastG, &g_lastS, st, ax ? ax->s : nullptr, ax ? ax->fork : nullptr, ax ? ax->join : nullptr));
     if (g_ev1) HIPCHK(hipEventRecord(g_ev1, st));
     return 0;
@@ -606,8 +615,8 @@ int agatha_amd_memcpy_h2d_async(void* stream, void* d_dst, const void* h_src, si
 { if (bytes) HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); return 0; }
 int agatha_amd_memcpy_d2h_async(void* stream, void* h_dst, const void* d_src, size_t bytes)
 { if (bytes) HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); return 0; }
-int agatha_amd_stream_create(void** stream) { if (!stream) return AGATHA_AMD_EINVAL; hipStream_t s; HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = (void*)s; return 0; }
-int agatha_amd_stream_destroy(void* stream) { if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream)); return 0; }
+int agatha_amd_stream_create(void** stream) { if (!stream) return AGATHA_AMD_EINVAL; hipStream_t s; HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = (void*)s; (void)aux_stream((void*)s); return 0; }
+int agatha_amd_stream_destroy(void* stream) { if (stream) { aux_stream_drop(stream); HIPCHK(hipStreamDestroy((hipStream_t)stream)); } return 0; }
 int agatha_amd_stream_synchronize(void* stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
 int agatha_amd_stream_query(void* stream)
 {

@@ -312,3 +312,35 @@ def test_cli_start_positions_of_ultra_long_reads(tmp_path):
         got = np.array([[int(f[0])] + [int(x.split("=")[1]) for x in f[1:]] for f in (l.split("\t") for l in r.stdout.strip().splitlines())], np.int64)
         assert (got == exp).all()
     assert exp[0, 0] > 100000
+
+
+@pytest.mark.parametrize("threads,packed", [(1, False), (2, True)])
+def test_cli_sustained_feed_of_sixteen_batches(tmp_path, threads, packed):
+    """The stream / batch manager behind gasal_aln_async over a sustained feed ({host fill, H2D, pack, sort, align,
+    D2H} stream-overlapped; reference gasal_align.cu:144-162,254-266 + test_prog.cpp:273-375): the pairs of the two files run eight
+    times over (AGATHA_AMD_REPEAT), sixteen batches of 9 000 pairs through two storages per host thread, host ASCII and host-packed
+    (-k).  Every batch prints the oracle's lines; no batch shows a pair taken over after the 50 ms time-out (each batch is a
+    persistent full-chip grid on a static schedule enqueued behind the other storage's); the CLI reports the seconds of its batch
+    loop (AGATHA_AMD_LOOP_STATS), which is what bench.py's `gasal_api.pipeline` turns into end-to-end GCUPS."""
+    a, rep = 9000, 8
+    n = 2 * a
+    qs, ts = synth.make_pairs(41, n, lambda r: int(r.integers(300, 900)), 0.03, 0.03, 0.04)
+    f1, f2, raw, stats, loop = (tmp_path / x for x in ("a.fa", "b.fa", "raw.log", "stats.txt", "loop.txt"))
+    write_fasta(f1, qs, header=">", width=10 ** 9)
+    write_fasta(f2, ts, header=">", width=10 ** 9)
+    P = O.make_params(w=200, z=100)
+    exp = np.stack(O.align_pairs(qs, ts, P, wide=True, threads=8), axis=1)
+    cmd = [MANUAL] + (["-k"] if packed else []) + ["-p", "-w", "200", "-z", "100", "-a", str(a), "-n", str(threads), str(f1), str(f2), str(raw)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, AGATHA_AMD_RAW_STATS=str(stats), AGATHA_AMD_LOOP_STATS=str(loop), AGATHA_AMD_REPEAT=str(rep),
+                                AGATHA_AMD_FORCE_INT16="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = parse(r.stdout)
+    assert len(got) == n * rep
+    # the virtual file is the two real batches over and over: thread t starts at pair t * (n * rep / threads), a multiple of a
+    match_batches(got, [exp[(k % n):(k % n) + a] for k in range(0, n * rep, a)])
+    lines = [l.split() for l in open(stats)]
+    assert len(lines) == 2 * rep and all(int(l[0]) == a for l in lines)
+    assert sum(int(l[6]) for l in lines) == 0, lines            # no pair was taken over after a time-out
+    sec, pairs, batches, nthr = open(loop).read().split()
+    assert int(pairs) == n * rep and int(batches) == 2 * rep and int(nthr) == threads and 0 < float(sec) < 60
