@@ -599,3 +599,19 @@ def test_two_wave_shape_with_value_steps_n_rows_and_pairs_started_over(eng):
     finally:
         agatha_amd.set_debug_option("force_choice", -1)
         agatha_amd.set_debug_option("force_int16", 1)
+
+
+def test_a_grid_larger_than_the_checkpoint_area_takes_no_checkpoints_beyond_it(eng):
+    """the checkpoint area is sized for the default persistent grid; with the max_blocks debug option above it
+    -- 3 workgroups per CU -- the lane groups beyond the area must simply do without checkpoints (they used to write past the end
+    of the caller's workspace: `ck_slots = 1 << 30`).  9 000 pairs of 1 050+ steps, a third of them broken so that pairs do go
+    back to checkpoints; results = the oracle's, and a second batch aligned right behind, whose workspace lies next to the first
+    one's, is intact."""
+    qs, ts = _broken_batch(91, 9000, 4200, 5200)
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
+    cus = 256
+    got, exp, st, kinds = _run_stats(eng, qs, ts, p, max_blocks=3 * cus, force_int16=1, ck_min_steps=1024)
+    assert all((g == e).all() for g, e in zip(got, exp))
+    assert st[15] > 0                   # pairs did go back to checkpoints (the lane groups inside the area)
+    got2, exp2, _, _ = _run_stats(eng, qs[:500], ts[:500], p, force_int16=1)
+    assert all((g == e).all() for g, e in zip(got2, exp2))

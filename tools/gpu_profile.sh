@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-r01}
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gasal-api"
 cat /sys/fs/cgroup/cpu.max > gpurun_out/cpu_quota.txt 2>&1; cat /sys/fs/cgroup/cpuset.cpus.effective >> gpurun_out/cpu_quota.txt 2>&1
 python3 -c "import os; print(len(os.sched_getaffinity(0)))" >> gpurun_out/cpu_quota.txt
 rocprofv3 -L > gpurun_out/counters_list.txt 2>&1
