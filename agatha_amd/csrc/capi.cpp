@@ -37,6 +37,7 @@ DebugOption g_opts[] = {
     {"force_choice", "AGATHA_AMD_FORCE_CHOICE", {-1}}, // >= 0: candidate index that takes the plain pairs
     {"no_migrate", "AGATHA_AMD_NO_MIGRATE", {0}},      // 1: pairs never move between lane groups (no preemptive schedule); -1: always when possible
     {"mig_timeout_us", "AGATHA_AMD_MIG_TIMEOUT_US", {50000}},   // wait for a suspended pair this long, then take it over
+    {"mig_fresh_timeout_us", "AGATHA_AMD_MIG_FRESH_TIMEOUT_US", {2000}},   // ... and this long when the other lane group has not even started the pair (its workgroup is not resident)
     {"mig_test_delay_us", "AGATHA_AMD_MIG_TEST_DELAY_US", {0}}, // tests: odd lane groups start this late
     {"prio_slice", "AGATHA_AMD_PRIO_SLICE", {-1}},     // > 0: SIMD partners alternate issue priority every 2^n ticks (10 ns each); -1: 2^15 on a static schedule, off otherwise; 0: off
     {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts); -1: also no priority by the length of a wave's pair on the latency shapes' work queue
@@ -48,7 +49,7 @@ DebugOption g_opts[] = {
     {"static_ck", "AGATHA_AMD_STATIC_CK", {1}},   // int16 kernel, static schedule, three register pairs per lane: 1 = checkpoints there as well (a pair that must be started over goes back in place), 0 = none (such a pair goes to the int32 kernel behind)
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {1024}},   // int16 kernel: pairs of at least this many steps take checkpoints (0: none do)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_CK_MIN_STEPS, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -358,6 +359,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         HIPCHK(hipMemsetAsync(timeline, 0, sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords, st));
     }
     L.mig_timeout_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TIMEOUT_US), 0);
+    L.mig_fresh_timeout_ticks = 100u * (unsigned)std::max(std::min(opt(OPT_MIG_FRESH_TIMEOUT_US), opt(OPT_MIG_TIMEOUT_US)), 0);
     L.mig_test_delay_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TEST_DELAY_US), 0);
     L.fast_margin = std::max(opt(OPT_FAST_MARGIN), 0);
     L.ck_buf = have_ck ? (uint32_t*)((char*)d_workspace + ck_off) : nullptr;

@@ -46,7 +46,8 @@ struct AlignLaunch {
     int* mig_state;                // device: [mig_slots + 1] state of the pair that crosses each group boundary
     uint32_t* mig_buf;             // device: suspended state of those pairs, mig_slot_dwords per boundary
     int mig_slot_dwords;
-    unsigned int mig_timeout_ticks;  // 100 MHz ticks a group waits for a pair to be suspended before it takes the pair over
+    unsigned int mig_timeout_ticks;  // 100 MHz ticks a group waits for a pair that another group is RUNNING to be suspended before it takes the pair over
+    unsigned int mig_fresh_timeout_ticks;   // ... and for a pair the other group has not even started (its workgroup is not resident)
     uint32_t* timeline;            // device (debug option "timeline"): per wave of the int16 kernel {start, end (100 MHz ticks), HW_ID, XCC_ID, steps, pairs}
     int prio_slice_bits;           // > 0: the two waves of a SIMD take turns at high issue priority, in slices of 2^bits ticks of the 100 MHz clock
     int* simd_steps;               // device: [2 workgroups][CU][SIMD] step counts the waves of a dealt single round tell each other

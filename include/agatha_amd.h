@@ -186,7 +186,9 @@ int agatha_amd_last_int16_config(void);
  *   scores and the band allow it), "force_choice" (>= 0: index of the candidate that takes the plain pairs, -1 = model),
  *   "no_deal" (1: no dealt first round), "no_migrate" (1: pairs never move between lane groups), "max_blocks"
  *   (> 0: cap of the persistent grids), "mig_timeout_us" (how long a lane group waits for a pair another group has to
- *   suspend before it takes the pair over, default 50000), "mig_test_delay_us" (tests: odd lane groups start late),
+ *   suspend before it takes the pair over, default 50000; "mig_fresh_timeout_us", default 2000, when that group has not even
+ *   started the pair: its workgroup is not resident), "mig_test_delay_us" (tests: odd lane groups start late), "no_split" (1: a
+ *   batch of mixed lengths is never split between the two int16 shapes), "prio_fine", "fast_margin", "ck_min_steps", "static_ck",
  *   "timeline" (1: waves record when and where they ran, agatha_amd_timeline), "prio_slice" / "prio_duty" (the
  *   time-sliced issue priority of the two waves that share a SIMD: slice length 2^n x 10 ns, -1 = automatic, 0 = off).
  * Returns AGATHA_AMD_EINVAL for an unknown name. */

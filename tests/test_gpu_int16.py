@@ -434,6 +434,39 @@ def test_migration_take_over_when_the_first_part_never_comes(eng):
         agatha_amd.set_debug_option("force_choice", -1)
 
 
+def test_a_lane_group_that_never_started_is_taken_over_after_a_short_grace(eng):
+    """Round 4: the only protection against a workgroup of the persistent grid that is not resident used
+    to be a fixed 50 ms.  A boundary whose state is still FRESH when its left neighbour needs the pair says that the right
+    neighbour has not even started -- nothing will arrive soon --, and the pair is taken over after mig_fresh_timeout_us (2 ms
+    by default); the long time-out is left for pairs that are RUNNING.  Forced here: odd lane groups start 30 ms late, the long
+    time-out stays at its 50 ms: the batch must end in well under that, with pairs taken over, and bit-exact."""
+    import time
+    qs, ts = _mig_batch(9000, 6, 200, 900)
+    p = dict(BASE, w=24)
+    agatha_amd.set_debug_option("force_choice", 0)
+    try:
+        with agatha_amd.debug_options(mig_test_delay_us=30000):
+            qb, qo, ql = WL.make_batch(qs)
+            tb, to, tl = WL.make_batch(ts)
+            exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=8)
+            b = eng.batch(qb, tb, qo, to, ql, tl)
+            try:
+                b.upload(); b.pack(); eng.synchronize()
+                e0, e1 = eng.event(), eng.event()
+                eng.record(e0); b.align(agatha_amd.Scores.make(**p)); eng.record(e1)
+                ms = eng.elapsed_ms(e0, e1)
+                b.download(); eng.synchronize()
+                got = [b.res_host[j].copy() for j in range(3)]
+                st, sched = b.step_stats(), b.schedule_info()
+            finally:
+                b.free()
+        assert sched[0] and _same(got, exp)
+        assert st[14] > 0                   # pairs were taken over ...
+        assert ms < 45.0, ms                # ... without anybody sitting out the long time-out (30 ms of forced delay + the work)
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
+
+
 def test_one_pair_on_two_cooperating_waves(eng):
     """Latency shape for windows of 129..256 blocks (bands 1017..2040 on long pairs, e.g. BASELINE's ultra-long config): one
     pair on the two waves of a 128-thread workgroup, <128, 1> -- the H hand-off of lane 63, the step's reduced maxima and
