@@ -39,8 +39,9 @@ VALU_GUIDE_PEAK_TOPS = 2 * VALU_PEAK_TOPS
 # algorithmic VALU lane-ops of one DP cell incl. the anti-diagonal maximum: 11 int32 ops per cell in the
 # int32 kernel; 10 packed ops per TWO cells in the packed-int16 kernel (2 score adds, 4 max, 1 sub, 2 key mads, 1 max3)
 OPS_PER_CELL = {"int32": 11.0, "int16": 5.0}
-# ... and on the int16 kernel's value steps (round 3) the maximum costs one packed instruction instead of three: 8 per two cells
-OPS_PER_CELL_VALUE_STEPS = 4.0
+# ... and on the int16 kernel's value steps the maximum is not computed per cell at all (round 4: bounds from the last row and
+# column of every block pair; round 3: one packed instruction per cell pair): 7 per two cells
+OPS_PER_CELL_VALUE_STEPS = 3.5
 
 
 # BASELINE.json's workload shapes; "pairs" is the size that fits one GPU comfortably (C2 is 100 k pairs on 8
@@ -467,7 +468,7 @@ def main():
                               "note": "lane-ops the recurrence itself needs per cell x cells/s over the measured VALU issue "
                                       "rate of the chip; the int16 kernel does two cells per packed lane-op.  ops_per_cell keeps "
                                       "round 2's count (10 per cell pair with H : column keys) so that rounds compare; value steps "
-                                      "need 8 per cell pair (frac_at_value_step_count)"},
+                                      "need 7 per cell pair since round 4 (frac_at_value_step_count)"},
         }
         if strong_leg is not None:
             SL = strong_leg

@@ -45,7 +45,9 @@ while time.time() < t_end:
     qb, qo, ql = WL.make_batch(qs); tb, to, tl = WL.make_batch(ts)
     exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=16)
     force_takeover = rng.random() < 0.25
-    for mode, opts in (("static", dict(mig_timeout_us=500, mig_test_delay_us=int(rng.integers(2000, 30000))) if force_takeover else {}),
+    # (no_migrate = -1: the static schedule whenever it is possible -- since round 4 the device does not choose it for a batch whose
+    #  longest pair is several times the average one, which these batches with their few long pairs are)
+    for mode, opts in (("static", dict(no_migrate=-1, mig_timeout_us=500, mig_fresh_timeout_us=int(rng.choice([100, 500, 2000])), mig_test_delay_us=int(rng.integers(2000, 30000))) if force_takeover else dict(no_migrate=-1)),
                        ("queue", dict(no_migrate=1))):
         vs = dict(fast_margin=int(rng.choice([0, 2, 16, 40])), ck_min_steps=int(rng.choice([0, 16, 4096])))       # value steps, checkpoints
         vs["static_ck"] = int(rng.integers(0, 2)); vs["fast_anchor"] = int(rng.integers(0, 2))
