@@ -347,7 +347,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         HIPCHK(agatha::launch_tb_plan(L, tb_gs, (unsigned long long)(cap / 4), tb_passes, off, pass, plan, st));
     }
     L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;
-    L.mig_slot_dwords = 0;
+    L.mig_slot_dwords = 0; L.mig_fallback = 0;
     L.timeline = nullptr;
     L.simd_steps = simd_steps;
     HIPCHK(hipMemsetAsync(simd_steps, 0, sizeof(int) * agatha::kSimdStepsInts, st));
@@ -378,12 +378,15 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     // histogram (record_kernel).  Debug options no_int16 / force_int16 / force_choice override it (A/B runs, tests).
     L.force_choice = opt(OPT_FORCE_CHOICE);
     L.choice = choice; L.totals = totals;
-    HIPCHK(agatha::plan_align(L, (int)window, opt(OPT_NO_INT16) != 0, opt(OPT_FORCE_INT16) != 0));
+    // (the int16 kernel keeps three flags of a pair in the top bits of its index)
+    HIPCHK(agatha::plan_align(L, (int)window, opt(OPT_NO_INT16) != 0 || n_alns >= (1u << 29), opt(OPT_FORCE_INT16) != 0));
     g_last16 = (L.ncand > 0 && L.cand[0].kind == 1) ? ((L.cand[0].G << 8) | L.cand[0].S) : 0;
     if (mig && L.ncand > 0 && L.cand[0].kind == 1 && L.cand[0].G < 64) {
         const int slots = L.cand[0].capacity, dwords = agatha::align16_mig_fields(L.cand[0].S / 2) * L.cand[0].G;
         if (slots <= agatha::kMigMaxSlots && (size_t)slots * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes) {
-            L.mig_enabled = opt(OPT_NO_MIGRATE) < 0 ? 2 : 1; L.mig_slots = slots; L.mig_slot_dwords = dwords;
+            // (room for a second state per boundary: the fallback of a pair that is suspended with a bound for its maximum)
+            const bool two = (size_t)slots * 2 * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes;
+            L.mig_enabled = opt(OPT_NO_MIGRATE) < 0 ? 2 : 1; L.mig_slots = slots; L.mig_slot_dwords = two ? 2 * dwords : dwords; L.mig_fallback = two ? 1 : 0;
             HIPCHK(hipMemsetAsync(mig_state, 0, sizeof(int) * ((size_t)slots + 1), st));
             HIPCHK(agatha::launch_schedule(L, st));
         }

@@ -45,7 +45,8 @@ struct AlignLaunch {
     int* sched;                    // device: [0] 1 = static schedule in force, [1] T = steps per lane group, [2] groups used
     int* mig_state;                // device: [mig_slots + 1] state of the pair that crosses each group boundary
     uint32_t* mig_buf;             // device: suspended state of those pairs, mig_slot_dwords per boundary
-    int mig_slot_dwords;
+    int mig_slot_dwords;           // (stride of a boundary's states in mig_buf)
+    int mig_fallback;              // 1: the stride holds TWO states, the suspended one and a fallback (the older checkpoint of a pair that was suspended with a bound for its maximum)
     unsigned int mig_timeout_ticks;  // 100 MHz ticks a group waits for a pair that another group is RUNNING to be suspended before it takes the pair over
     unsigned int mig_fresh_timeout_ticks;   // ... and for a pair the other group has not even started (its workgroup is not resident)
     uint32_t* timeline;            // device (debug option "timeline"): per wave of the int16 kernel {start, end (100 MHz ticks), HW_ID, XCC_ID, steps, pairs}
@@ -91,7 +92,7 @@ constexpr int kMigPairOverheadSteps = 4;
 constexpr int kMigMaxSlots = 16384;
 constexpr int kSimdStepsInts = 2 * 4 * 1024;          // (up to 1024 CUs)
 constexpr int kTimelineWaves = 4096, kTimelineDwords = 8;
-constexpr size_t kMigBufBytes = (size_t)68 << 20;
+constexpr size_t kMigBufBytes = (size_t)136 << 20;      // (two states of <= 8.2 KB per lane group boundary, 8 192 of them)
 
 // window_blocks = blocks that can be live on one block-anti-diagonal.  plan_align fills L.cand / L.ncand (int16 kernel if
 // usable and not disabled, int32 throughput shape = smallest (G, S) covering the window, int32 latency shape = 64 lanes

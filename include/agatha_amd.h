@@ -61,7 +61,7 @@ int agatha_amd_max_band(void);
 
 /* bytes of device scratch agatha_amd_align() needs for up to max_n_alns pairs (replaces the reference's
  * 0.98 GB/stream global_buffer + pinned host_buffer, ctors.cpp:89-90: this is ~5 B per pair + 64 KiB up to 4096 pairs;
- * larger batches add ~68 MiB for the pairs that are suspended and resumed by another lane group when the batch is larger
+ * larger batches add ~136 MiB for the pairs that are suspended and resumed by another lane group when the batch is larger
  * than one round of lane groups -- a caller that passes less gets the work queue instead, never an error) */
 size_t agatha_amd_workspace_bytes(uint32_t max_n_alns);
 /* The same plus, when the sequences can be long (ceil(query / 8) + ceil(target / 8) >= 1024 -- the debug option ck_min_steps --, or a length given as 0 =
