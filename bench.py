@@ -359,6 +359,7 @@ def main():
     ap.add_argument("--no-gasal-api", action="store_true", help="skip the timing of the CLI / GASAL API by the reference's raw.log protocol")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the sustained stream/batch-manager leg (gasal_aln_async over 16 batches)")
     ap.add_argument("--strong-pairs", type=int, default=100000, help="N > 1: pairs of the ONE sharded batch of the `strong` object (BASELINE configs[2]); 0 = no strong leg")
+    ap.add_argument("--force-strong-leg", action="store_true", help="run the strong leg under a launcher with ONE rank as well (checks the N > 1 code path on a 1-GPU box)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     if a.pairs <= 0:
@@ -395,7 +396,7 @@ def main():
 
     L = run_leg(ctx, a.config, a.pairs, a.scaling, a.steps, a.warmup, a.n_run_frac)
     strong_leg = None
-    if use_dist and world > 1 and a.scaling == "weak" and a.strong_pairs > 0:
+    if use_dist and (world > 1 or a.force_strong_leg) and a.scaling == "weak" and a.strong_pairs > 0:
         # the sharded batch BASELINE.json names for 8 GPUs (configs[2]: 100 000 HiFi pairs), strong scaling, in the same run
         strong_leg = run_leg(ctx, "C2", a.strong_pairs, "strong", min(a.steps, 3) if a.steps else 0, 1)
 
