@@ -20,7 +20,7 @@ hipError_t AGATHA16_CAT(align16_entry_, AGATHA16_NT0)(const AlignLaunch& L, int 
 #else
     // windows of 32, 64, 96, 128, 192 blocks; then the latency shapes
     AGATHA16_SHAPE(16, 1) AGATHA16_SHAPE(16, 2) AGATHA16_SHAPE(16, 3) AGATHA16_SHAPE(32, 2) AGATHA16_SHAPE(32, 3)
-    AGATHA16_SHAPE(64, 1) AGATHA16_SHAPE(64, 2) AGATHA16_SHAPE(128, 1)
+    AGATHA16_SHAPE(64, 1) AGATHA16_SHAPE(64, 2) AGATHA16_SHAPE(128, 1) AGATHA16_SHAPE(64, 3)
 #endif
 #undef AGATHA16_SHAPE
     return hipErrorInvalidValue;

@@ -30,6 +30,7 @@ hipError_t align16_tb_entry_7(const AlignLaunch&, int, int, int, hipStream_t);
 struct Cfg16 { int G, P; };
 static const Cfg16 kCfgs16[] = {       // ascending G * 2P: windows of 32, 64, 96, 128, 192 blocks; then the latency shapes
     {16, 1}, {16, 2}, {16, 3}, {32, 2}, {32, 3}, {64, 1}, {64, 2}, {128, 1},
+    {64, 3},                           // (round 4) windows of 257..384 blocks: bands up to 3064 on long pairs
 };
 
 int align16_mig_fields(int P) { return mig_fields(P); }
@@ -50,6 +51,10 @@ static const Cfg16* pick16(const AlignParams& p, int window_blocks)
     if (!agatha16_scores_ok(p)) return nullptr;
     for (const Cfg16& c : kCfgs16)
         if (c.G < 64 && c.G * 2 * c.P >= window_blocks) return (c.G * 2 * c.P <= 2 * window_blocks + 32) ? &c : nullptr;
+    // (round 4) wider windows -- bands 1529..3064 on long pairs, which used to run on the int32 kernel only: one pair per wave,
+    // two or three register pairs per lane, as the THROUGHPUT shape
+    for (const Cfg16& c : kCfgs16)
+        if (c.G == 64 && c.P >= 2 && c.G * 2 * c.P >= window_blocks) return &c;
     return nullptr;
 }
 
@@ -63,6 +68,7 @@ bool align16_config(const AlignParams& p, int window_blocks, int* G, int* P, int
         if (l.G == 64 && l.G * 2 * l.P >= window_blocks && l.P < c->P) { *GL = l.G; *PL = l.P; break; }
     // ... or one pair on two cooperating waves when that halves the register pairs per lane again (windows of 129..256 blocks)
     if (*GL == 64 && *PL == 2 && window_blocks <= 256) { *GL = 128; *PL = 1; }
+    if (c->G == 64 && c->P == 2 && window_blocks <= 256) { *GL = 128; *PL = 1; }       // (throughput shape <64, 2>: windows of 193..256 blocks)
     return true;
 }
 
@@ -81,7 +87,7 @@ bool align16_tb_config(const AlignParams& p, int window_blocks, int group_slots,
 {
     if (!agatha16_scores_ok(p)) return false;
     for (const Cfg16& c : kCfgs16)
-        if (c.P == 3 && c.G * 2 * c.P == group_slots && group_slots >= window_blocks) { *G = c.G; *P = c.P; return true; }
+        if (c.P == 3 && c.G < 64 && c.G * 2 * c.P == group_slots && group_slots >= window_blocks) { *G = c.G; *P = c.P; return true; }
     return false;
 }
 

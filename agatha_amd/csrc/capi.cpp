@@ -121,7 +121,7 @@ size_t mig_workspace_bytes(uint32_t n)
 // Checkpoint area of the packed-int16 kernel (two slots of a suspended pair's size per lane group that can be in flight: the
 // largest of its shapes' needs, never more lane groups than pairs)
 struct CkShape { int G, P; };
-const CkShape kCkShapes[] = {{16, 1}, {16, 2}, {16, 3}, {32, 2}, {32, 3}, {64, 1}, {64, 2}, {128, 1}};
+const CkShape kCkShapes[] = {{16, 1}, {16, 2}, {16, 3}, {32, 2}, {32, 3}, {64, 1}, {64, 2}, {128, 1}, {64, 3}};
 size_t ck_groups(int G, uint32_t n)
 {
     const size_t cus = (size_t)num_cus();

@@ -648,3 +648,28 @@ def test_a_grid_larger_than_the_checkpoint_area_takes_no_checkpoints_beyond_it(e
     assert st[15] > 0                   # pairs did go back to checkpoints (the lane groups inside the area)
     got2, exp2, _, _ = _run_stats(eng, qs[:500], ts[:500], p, force_int16=1)
     assert all((g == e).all() for g, e in zip(got2, exp2))
+
+
+@pytest.mark.parametrize("w", [1600, 2047, 2300, 3064])
+def test_bands_beyond_1528_run_on_the_int16_kernel(eng, w):
+    """Round 4 (VERDICT r3 missing #5): windows of 193..384 blocks -- bands 1529..3064 on long pairs -- had no int16 shape and ran
+    on the int32 kernel at half the rate.  <64, 2> (one pair per wave, two register pairs per lane) and the new <64, 3> take them as
+    throughput shapes; <128, 1> stays the latency shape up to 256 blocks.  Long pairs with large indels (so that the band's edges
+    matter), broken ones (z-drop) and one cut diagonal per band against the oracle; nothing handed back to the int32 kernel."""
+    rng = np.random.default_rng(w)
+    qs, ts = [], []
+    for k in range(20):
+        ref = WL.random_seq(rng, int(rng.integers(14000, 22000)))
+        rd = WL.mutate(rng, ref, 0.03, 0.03, 0.04)
+        if k % 4 == 1:          # a large deletion / insertion: the path runs along the band's edge
+            cut = int(rng.integers(1000, min(w, 2500))); at = int(rng.integers(2000, 8000))
+            rd = np.concatenate([rd[:at], rd[at + cut:]]) if k % 8 == 1 else np.concatenate([rd[:at], WL.random_seq(rng, cut), rd[at:]])
+        if k % 5 == 0:
+            rd = np.concatenate([rd[:rd.size // 2], WL.random_seq(rng, rd.size // 2)])          # breaks: z-drop
+        qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    p = dict(BASE, w=w)
+    got, exp, st, kinds = _run_stats(eng, qs, ts, p, force_int16=1)
+    W = (w + 7) // 8
+    assert _run_stats.choice[0] == "int16" and _run_stats.choice[1] in (64, 128) and _run_stats.choice[1] * _run_stats.choice[2] >= W + 1
+    assert all((g == e).all() for g, e in zip(got, exp))
+    assert kinds[2] == 0 and st[0] + st[1] > 0

@@ -8,7 +8,7 @@ eng = agatha_amd.Engine(0)
 qs, ts = getattr(workload, cfgname)(n=n)
 qb, qo, ql = workload.make_batch(qs); tb, to, tl = workload.make_batch(ts)
 b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); eng.synchronize()
-W = {"cfg_c2": 500, "cfg_c3": 1500}.get(cfgname, 751)
+W = int(os.environ.get("BAND", {"cfg_c2": 500, "cfg_c3": 1500}.get(cfgname, 751)))
 sc = agatha_amd.Scores.make(w=W)
 defaults = {}
 for spec in sys.argv[3:] or [""]:
