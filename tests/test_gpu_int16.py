@@ -82,6 +82,9 @@ def _expected_int16_config(p):
     for G, S in ((16, 2), (16, 4), (16, 6), (32, 4), (32, 6)):
         if G * S >= W + 1:
             return (G, S) if G * S <= 2 * (W + 1) + 32 else None
+    for G, S in ((64, 4), (64, 6)):             # (round 4) windows of 193..384 blocks: one pair per wave as the throughput shape
+        if G * S >= W + 1:
+            return (G, S)
     return None
 
 
@@ -92,8 +95,8 @@ def _expected_int16_config(p):
                          ids=lambda p: "m%dx%dq%dr%ds%dz%dw%d" % (p["m"], p["x"], p["q"], p["r"], p["s"], p["z"], p["w"]))
 def test_int16_kernel_matches_oracle(eng, p):
     """Cut diagonals, windows (16x2 ... 32x6 slots), slice widths, z-drop on/off/immediate, a scoring at the edge of the
-    int16 kernel's domain, and bands the launcher must leave to the int32 kernel (w = 1500 / 2000: in-band values can
-    spread too far for the int16 zones; w = 15: too narrow)."""
+    int16 kernel's domain, the wide windows of round 4 (w = 2000: <64, 2>), and a band the launcher must leave to the int32
+    kernel (w = 15: too narrow)."""
     hi = 14000 if p["w"] <= 1000 else 30000
     qs, ts = WL.cfg_c4(n=160 if p["w"] <= 1000 else 96, seed=31 + p["w"], lo=50, hi=hi)
     got, exp = _run(eng, qs, ts, p)
