@@ -6,7 +6,7 @@ package is a thin ctypes binding of that C-ABI for tests, bench.py and scripting
 loading fails loudly when the library is missing.
 """
 from .engine import (Engine, Scores, DeviceBatch, load_library, library_path, build_library,  # noqa: F401
-                     AgathaError, set_debug_option, get_debug_option, debug_options, pack_host)
+                     AgathaError, set_debug_option, get_debug_option, debug_options, pack_host, pack2_host)
 
 __all__ = ["Engine", "Scores", "DeviceBatch", "load_library", "library_path", "build_library", "AgathaError",
-           "set_debug_option", "get_debug_option", "debug_options", "pack_host"]
+           "set_debug_option", "get_debug_option", "debug_options", "pack_host", "pack2_host"]

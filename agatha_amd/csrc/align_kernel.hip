@@ -118,6 +118,41 @@ pack_kernel(const uint4* __restrict__ in16, uint2* __restrict__ out8, uint32_t n
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 2-bit codes + N mask -> the 4-bit words the kernels read (round 4: the "2-bit-packed" input of north_star; SURVEY.md 8 f3's
+// second half).  Per 8 bases one uint16 of codes (A 0, C 1, G 2, T 3; base k in bits 15-2k..14-2k, first base on top, like the
+// 4-bit layout) and one byte of mask (bit 7-k: base k is N -- or padding, or any other letter: the format carries ACGT + N only):
+// 3 bits per base over PCIe instead of 4 (isPacked) or 8 (ASCII).  One lane per 16 bases: 32-bit codes word + 16-bit mask in,
+// two 4-bit words out, coalesced.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t unpack2_word(uint32_t codes16, uint32_t mask8)
+{
+    uint32_t v = 0;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+        const uint32_t c = (codes16 >> (14 - 2 * k2)) & 3u;
+        const uint32_t nib = ((mask8 >> (7 - k2)) & 1u) ? 14u : ((0x4731u >> (4 * c)) & 15u);       // A 1, C 3, G 7, T 4 (c & 0xF of the ASCII letters)
+        v |= nib << (28 - 4 * k2);
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+unpack2_kernel(const uint16_t* __restrict__ codes, const uint8_t* __restrict__ nmask, uint32_t nwords, uint32_t* __restrict__ out)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nwords; t += stride) out[t] = unpack2_word(codes[t], nmask[t]);
+}
+
+hipError_t launch_unpack2(const uint16_t* codes, const uint8_t* nmask, uint32_t nwords, uint32_t* packed, hipStream_t st)
+{
+    uint32_t blocks = (nwords + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(unpack2_kernel, dim3(blocks), dim3(256), 0, st, codes, nmask, nwords, packed);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Prepass: flag the pairs whose sequences hold a letter outside {A, C, G, T, N} (any case).  The alignment kernel's
 // score profile only has rows for those five classes; flagged pairs use its compare path.  One wave per pair.
 // ---------------------------------------------------------------------------------------------------

@@ -223,6 +223,35 @@ int agatha_amd_pack_host(const uint8_t* h_unpacked, size_t nbytes, uint32_t* h_p
     return 0;
 }
 
+long agatha_amd_pack2_host(const uint8_t* h_unpacked, size_t nbytes, uint16_t* h_codes, uint8_t* h_nmask)
+{
+    if (!h_unpacked || !h_codes || !h_nmask || (nbytes % 8) != 0) return AGATHA_AMD_EINVAL;
+    // code of the low nibble of an ASCII letter (any case): A 1 -> 0, C 3 -> 1, G 7 -> 2, T 4 -> 3; everything else, N included: mask
+    static const int8_t code_of[16] = {-1, 0, -1, 1, 3, -1, -1, 2, -1, -1, -1, -1, -1, -1, -1, -1};
+    long other = 0;
+    for (size_t w = 0; w < nbytes / 8; w++) {
+        uint32_t codes = 0, mask = 0;
+        for (int k = 0; k < 8; k++) {
+            const uint8_t ch = h_unpacked[8 * w + k];
+            const int c = code_of[ch & 15u];
+            // (the low nibble alone cannot tell 'A' from 'Q': the letter itself must be one of ACGT, any case)
+            const uint8_t up = (uint8_t)(ch & 0xDFu);
+            const bool acgt = c >= 0 && (up == 'A' || up == 'C' || up == 'G' || up == 'T');
+            if (acgt) codes |= (uint32_t)c << (14 - 2 * k);
+            else { mask |= 1u << (7 - k); if (up != 'N') other++; }
+        }
+        h_codes[w] = (uint16_t)codes; h_nmask[w] = (uint8_t)mask;
+    }
+    return other;
+}
+
+int agatha_amd_unpack2(void* stream, const uint16_t* d_codes, const uint8_t* d_nmask, uint32_t nbytes, uint32_t* d_packed)
+{
+    if (!d_codes || !d_nmask || !d_packed || nbytes == 0 || (nbytes % 8) != 0) return AGATHA_AMD_EINVAL;
+    HIPCHK(agatha::launch_unpack2(d_codes, d_nmask, nbytes / 8, d_packed, (hipStream_t)stream));
+    return 0;
+}
+
 int agatha_amd_seq_ops(void* stream, const uint8_t* d_unpacked, uint32_t* d_packed, const uint32_t* d_lens,
                        const uint32_t* d_offsets, const uint8_t* d_ops, uint32_t n_seqs)
 {

@@ -143,5 +143,7 @@ hipError_t launch_tb_plan(const AlignLaunch& L, int group_slots, unsigned long l
 hipError_t launch_align_tb(const AlignLaunch& L, int window_blocks, int pass, hipStream_t st);
 hipError_t launch_backtrace(const AlignLaunch& L, int group_slots, int pass, uint8_t* cigar, uint32_t* n_ops, hipStream_t st);
 hipError_t launch_pack(const uint8_t* unpacked, uint32_t nbytes, uint32_t* packed, hipStream_t st);
+// 2-bit codes + N mask (one uint16 + one byte per 8 bases) -> nwords 4-bit words
+hipError_t launch_unpack2(const uint16_t* codes, const uint8_t* nmask, uint32_t nwords, uint32_t* packed, hipStream_t st);
 
 }  // namespace agatha

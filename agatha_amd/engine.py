@@ -95,6 +95,9 @@ def load_library():
     lib.agatha_amd_timeline.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.agatha_amd_schedule_info.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
     lib.agatha_amd_split_info.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
+    lib.agatha_amd_pack2_host.argtypes = [vp, C.c_size_t, vp, vp]
+    lib.agatha_amd_pack2_host.restype = C.c_long
+    lib.agatha_amd_unpack2.argtypes = [vp, vp, vp, C.c_uint32, vp]
     lib.agatha_amd_step_stats.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint)]
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.agatha_amd_free.argtypes = [vp]
@@ -119,7 +122,7 @@ EXPORTS = [
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_workspace_bytes_long", "agatha_amd_pack", "agatha_amd_pack_host",
     "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_starts_scratch_bytes", "agatha_amd_align_starts", "agatha_amd_traceback_pair_bytes",
     "agatha_amd_traceback_scratch_bytes",
-    "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_split_info", "agatha_amd_step_stats", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_split_info", "agatha_amd_pack2_host", "agatha_amd_unpack2", "agatha_amd_step_stats", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -134,6 +137,20 @@ def pack_host(unpacked):
     out = np.empty(u.size // 8, np.uint32)
     _chk(lib, lib.agatha_amd_pack_host(u.ctypes.data, u.size, out.ctypes.data))
     return out
+
+
+def pack2_host(unpacked):
+    """2-bit codes + N mask of a padded ASCII batch (agatha_amd_pack2_host): -> (codes uint16[n/8], nmask uint8[n/8], letters that
+    were neither ACGT nor N and became N)."""
+    lib = load_library()
+    u = np.ascontiguousarray(unpacked, np.uint8)
+    if u.size % 8:
+        raise AgathaError("the batch must be padded to a multiple of 8 bytes")
+    codes, nmask = np.zeros(u.size // 8, np.uint16), np.zeros(u.size // 8, np.uint8)
+    other = lib.agatha_amd_pack2_host(u.ctypes.data, u.size, codes.ctypes.data, nmask.ctypes.data)
+    if other < 0:
+        raise AgathaError(f"agatha_amd_pack2_host: {other}")
+    return codes, nmask, int(other)
 
 
 def set_debug_option(name, value):
@@ -248,6 +265,26 @@ class DeviceBatch:
         self._packed_host = (pq, pt)          # keep alive until the copies have run
         _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, self.d_pk_q.ptr, pq.ctypes.data, pq.nbytes))
         _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, self.d_pk_t.ptr, pt.ctypes.data, pt.nbytes))
+        for d, h in zip(self.d_meta, self.host[2:]):
+            _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, d.ptr, h.ctypes.data, h.nbytes))
+
+    def upload_packed2(self, codes_q, nmask_q, codes_t, nmask_t, stream=None):
+        """2-bit codes + N mask (agatha_amd_pack2_host: one uint16 + one byte per 8 bases of the padded batch layout; 3 bits per
+        base over PCIe): the two arrays of each side go to the (otherwise unused) unpacked device buffer and agatha_amd_unpack2
+        turns them into the 4-bit words the kernels read, in the place of pack().  ACGT + N only."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        keep = []
+        for codes, nmask, nbytes, d_unp, d_pk in ((codes_q, nmask_q, self.qbytes, self.d_unp_q, self.d_pk_q), (codes_t, nmask_t, self.tbytes, self.d_unp_t, self.d_pk_t)):
+            c = np.ascontiguousarray(codes, np.uint16); m = np.ascontiguousarray(nmask, np.uint8)
+            if c.size * 8 != nbytes or m.size * 8 != nbytes:
+                raise AgathaError("2-bit batches must hold one uint16 and one mask byte per 8 bytes of the unpacked batch layout")
+            keep += [c, m]
+            off_m = (c.nbytes + 255) // 256 * 256           # codes at the start of the unpacked buffer, the mask behind them (3/8 of its size)
+            _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, d_unp.ptr, c.ctypes.data, c.nbytes))
+            _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, d_unp.ptr + off_m, m.ctypes.data, m.nbytes))
+            _chk(lib, lib.agatha_amd_unpack2(st, d_unp.ptr, d_unp.ptr + off_m, nbytes, d_pk.ptr))
+        self._packed_host = tuple(keep)
         for d, h in zip(self.d_meta, self.host[2:]):
             _chk(lib, lib.agatha_amd_memcpy_h2d_async(st, d.ptr, h.ctypes.data, h.nbytes))
 

@@ -80,6 +80,17 @@ int agatha_amd_pack(void* stream, const uint8_t* d_unpacked, uint32_t nbytes, ui
  * Plain host pointers, nbytes a multiple of 8, h_packed holds nbytes/8 words.  Synchronous. */
 int agatha_amd_pack_host(const uint8_t* h_unpacked, size_t nbytes, uint32_t* h_packed);
 
+/* 2-bit codes + N mask (round 4; north_star's "2-bit-packed reference/query"): per 8 bases of the padded batch one
+ * uint16 of codes (A 0, C 1, G 2, T 3; base k in bits 15-2k..14-2k) and one byte of mask (bit 7-k: base k is N, padding, or any
+ * letter outside ACGT -- the format carries ACGT + N only): 3 bits per base over PCIe instead of 4 (agatha_amd_pack_host) or 8.
+ * agatha_amd_pack2_host packs on the host (nbytes a multiple of 8; h_codes holds nbytes/8 uint16, h_nmask nbytes/8 bytes) and
+ * returns the number of letters that were neither ACGT nor N and went into the mask as N (>= 0; a caller that must keep such
+ * letters -- they score as mismatches against everything in the reference, gasal_kernels.h:48-50 -- ships ASCII or 4-bit words
+ * instead), or a negative error code.  agatha_amd_unpack2 turns the two device arrays into the nbytes/8 4-bit words every
+ * kernel reads; use it in the place of agatha_amd_pack(). */
+long agatha_amd_pack2_host(const uint8_t* h_unpacked, size_t nbytes, uint16_t* h_codes, uint8_t* h_nmask);
+int agatha_amd_unpack2(void* stream, const uint16_t* d_codes, const uint8_t* d_nmask, uint32_t nbytes, uint32_t* d_packed);
+
 /* Per-sequence reverse / complement of one side of a batch, AFTER agatha_amd_pack().  Replaces the
  * gasal_reversecomplement_kernel launch (gasal_align.cu:199-213; kernel pack_rc_seqs.h:56-212).  d_ops[k] bit 0 = reverse,
  * bit 1 = complement (operation_on_seq, gasal.h:66-71); sequences with op 0 are left untouched.  Needs the unpacked ASCII

@@ -45,7 +45,7 @@ def test_library_reports_limits_without_a_gpu():
     assert lib.agatha_amd_max_band() >= 1500          # BASELINE config 3 needs band 1500
     assert lib.agatha_amd_workspace_bytes(4096) < (1 << 20)
     # batches that can exceed one round of lane groups also carry the areas of the preemptive schedule (suspended pairs)
-    assert lib.agatha_amd_workspace_bytes(8192) < (80 << 20)          # the reference: 0.98 GB per stream (ctors.cpp:89)
+    assert lib.agatha_amd_workspace_bytes(8192) < (160 << 20)         # (two states per lane-group boundary since round 4) the reference: 0.98 GB per stream (ctors.cpp:89)
     assert lib.agatha_amd_strerror(-2).decode().startswith("band")
 
 
@@ -139,3 +139,25 @@ def test_host_packer_matches_the_pack_layout():
     for n in [8 * k for k in range(1, 20)] + [4096, 100008]:
         a = letters[rng.integers(0, letters.size, n)].copy()
         assert (agatha_amd.pack_host(a) == O.pack(a)).all(), n
+
+
+def test_two_bit_host_packer_round_trips_through_the_four_bit_layout():
+    """agatha_amd_pack2_host (2-bit codes + N mask, 3 bits per base: north_star's "2-bit-packed" input): unpacking its output on
+    the CPU by the rule the device kernel uses gives the 4-bit words of the ordinary packing (pack_rc_seqs.h:21-33) wherever the
+    letters are ACGT or N in any case; every other letter becomes N and is counted."""
+    import numpy as np
+    import agatha_amd
+    rng = np.random.default_rng(8)
+    a = rng.choice(np.frombuffer(b"ACGTNacgtn", np.uint8), 8 * 1001).astype(np.uint8)
+    codes, nmask, other = agatha_amd.pack2_host(a)
+    assert other == 0 and codes.dtype == np.uint16 and nmask.dtype == np.uint8 and codes.size == nmask.size == 1001
+    lut = np.array([1, 3, 7, 4], np.uint32)
+    words = np.zeros(1001, np.uint32)
+    for k in range(8):
+        c = (codes.astype(np.uint32) >> (14 - 2 * k)) & 3
+        nib = np.where((nmask >> (7 - k)) & 1, 14, lut[c]).astype(np.uint32)
+        words |= nib << np.uint32(28 - 4 * k)
+    assert (words == agatha_amd.pack_host(a)).all()
+    b = a.copy(); b[5] = ord("R"); b[77] = ord("q"); b[78] = ord("-")          # ('q' & 15 = 1 like 'A': the letter itself is looked at)
+    c2, m2, other2 = agatha_amd.pack2_host(b)
+    assert other2 == 3 and (m2[0] >> (7 - 5)) & 1 and (m2[9] >> (7 - 5)) & 1 and (m2[9] >> (7 - 6)) & 1

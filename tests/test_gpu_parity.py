@@ -300,3 +300,34 @@ def test_start_positions_against_the_oracle(eng):
             b.free()
         assert (gq == xq).all() and (gt == xt).all()
         assert (gq > 0).sum() > 50 and (gt > 0).sum() > 50 and (gq >= 0).all() and (gq <= eq).all() and (gt <= et).all()
+
+
+def test_two_bit_input_with_n_mask(eng):
+    """2-bit codes + N mask (agatha_amd_pack2_host / agatha_amd_unpack2; `north_star`'s "2-bit-packed reference/query", SURVEY.md
+    8 f3's second half): the device words equal the pack kernel's, and the batch aligns to the oracle's results -- with runs of
+    N in both sequences (the mask), lower-case letters, ragged lengths."""
+    import agatha_amd
+    rng = np.random.default_rng(12)
+    qs, ts = synth.cfg_c4(n=64, seed=5, lo=50, hi=3000)
+    qs = [bytes(q) for q in qs]
+    ts = [bytes(t) for t in ts]
+    for k in range(0, 64, 5):               # runs of N, lower case
+        q = bytearray(qs[k]); a = int(rng.integers(0, max(1, len(q) - 40))); q[a:a + 30] = b"N" * min(30, len(q) - a); qs[k] = bytes(q)
+        ts[k] = ts[k].lower() if k % 2 else ts[k][:len(ts[k]) // 2] + b"n" * 7 + ts[k][len(ts[k]) // 2:]
+    qb, qo, ql = O.make_batch(qs)
+    tb, to, tl = O.make_batch(ts)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(), wide=True, model=O.MODEL_SLICES, threads=4)
+    cq, mq, oq = agatha_amd.pack2_host(qb)
+    ct, mt, ot = agatha_amd.pack2_host(tb)
+    assert oq == 0 and ot == 0
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload_packed2(cq, mq, ct, mt)
+        pq, pt = b.packed_host()
+        assert (pq == O.pack(qb)).all() and (pt == O.pack(tb)).all()
+        b.align(agatha_amd.Scores.make()); b.download(); eng.synchronize()
+        got = [b.res_host[j].copy() for j in range(3)]
+    finally:
+        b.free()
+    for g, e in zip(got, exp):
+        assert (np.asarray(g) == np.asarray(e)).all()
