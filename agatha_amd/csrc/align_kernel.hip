@@ -449,6 +449,7 @@ record_kernel(AlignLaunch L, AlignLaunch* rec, const uint32_t* __restrict__ hist
             float c = 3.4e38f; uint32_t b = 0;
             for (int j = 0; j < 256; j++) if (s_cost[j] < c) { c = s_cost[j]; b = s_bucket[j]; }
             if (c < 0.93f * bestc && b > 0u && b < nbuckets) n_long = hist[b];
+            if (L.force_split > 0) n_long = (uint32_t)min(L.force_split, L.n - 1);
         }
     }
     if (t == 0) {
