@@ -228,7 +228,8 @@ int agatha_amd_split_info(void* stream, const void* d_workspace, uint32_t n_alns
 int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_alns, int out[3]);
 
 /* Diagnostics: what the packed-int16 kernel's steps were in the last agatha_amd_align() on this workspace: out[0] = wave-steps
- * on packed maxima of H alone ("value steps"), out[1] = wave-steps with H : column keys ("key steps": a pair's last steps,
+ * without anti-diagonal maxima inside the blocks ("value steps": the running maximum and the anti-diagonal maxima are bounded by
+ * the last row and column of every block), out[1] = wave-steps with H : column keys ("key steps": a pair's last steps,
  * pairs that were started over), out[2] = pairs started over on key steps (z-drop came into reach on a value step, or the
  * pair ended without knowing the cell of its maximum) from their first step, out[3] = pairs started, out[15] = pairs taken back to a
  * checkpoint instead, out[24] = pairs handed to the int32 kernel instead (static schedule without checkpoints: debug option
