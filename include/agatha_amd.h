@@ -200,6 +200,8 @@ int agatha_amd_last_int16_config(void);
  *   suspend before it takes the pair over, default 50000; "mig_fresh_timeout_us", default 2000, when that group has not even
  *   started the pair: its workgroup is not resident), "mig_test_delay_us" (tests: odd lane groups start late), "no_split" (1: a
  *   batch of mixed lengths is never split between the two int16 shapes), "prio_fine", "fast_margin", "ck_min_steps", "static_ck",
+ *   "ck_shift" / "ck_newer" (spacing of the int16 kernel's checkpoints; which of the two a pair goes back to), "force_split" /
+ *   "lat_blocks" (experiments with the split),
  *   "timeline" (1: waves record when and where they ran, agatha_amd_timeline), "prio_slice" / "prio_duty" (the
  *   time-sliced issue priority of the two waves that share a SIMD: slice length 2^n x 10 ns, -1 = automatic, 0 = off).
  * Returns AGATHA_AMD_EINVAL for an unknown name. */
