@@ -227,10 +227,9 @@ int agatha_amd_pack_host(const uint8_t* h_unpacked, size_t nbytes, uint32_t* h_p
     return 0;
 }
 
-long agatha_amd_pack2_host(const uint8_t* h_unpacked, size_t nbytes, uint16_t* h_codes, uint8_t* h_nmask)
+// code of the low nibble of an ASCII letter (any case): A 1 -> 0, C 3 -> 1, G 7 -> 2, T 4 -> 3; everything else, N included: mask
+static long pack2_host_scalar(const uint8_t* h_unpacked, size_t nbytes, uint16_t* h_codes, uint8_t* h_nmask)
 {
-    if (!h_unpacked || !h_codes || !h_nmask || (nbytes % 8) != 0) return AGATHA_AMD_EINVAL;
-    // code of the low nibble of an ASCII letter (any case): A 1 -> 0, C 3 -> 1, G 7 -> 2, T 4 -> 3; everything else, N included: mask
     static const int8_t code_of[16] = {-1, 0, -1, 1, 3, -1, -1, 2, -1, -1, -1, -1, -1, -1, -1, -1};
     long other = 0;
     for (size_t w = 0; w < nbytes / 8; w++) {
@@ -247,6 +246,49 @@ long agatha_amd_pack2_host(const uint8_t* h_unpacked, size_t nbytes, uint16_t* h
         h_codes[w] = (uint16_t)codes; h_nmask[w] = (uint8_t)mask;
     }
     return other;
+}
+
+__attribute__((target("avx2,popcnt"))) static long pack2_host_avx2(const uint8_t* a, size_t nbytes, uint16_t* h_codes, uint8_t* h_nmask)
+{
+    // 32 bases -> 4 code words + 4 mask bytes per iteration.  Two table lookups on the low nibble give the 2-bit code and the letter
+    // that nibble must belong to (upper case); bases that are not that letter are masked.  The codes of a word are combined by two
+    // multiply-adds (4 * even + odd, then 16 * even + odd: one byte per four bases) and a shift; the mask bits come from movemask,
+    // bit-reversed per byte (the first base sits in the top bit).
+    static uint8_t rev8[256];
+    static const bool rev_ready = [] { for (int v = 0; v < 256; v++) { int r = 0; for (int b = 0; b < 8; b++) if (v & (1 << b)) r |= 0x80 >> b; rev8[v] = (uint8_t)r; } return true; }();
+    (void)rev_ready;
+    const __m256i lo4 = _mm256_set1_epi8(0x0F), upper = _mm256_set1_epi8((char)0xDF), letter_n = _mm256_set1_epi8('N');
+    const __m256i code_lut = _mm256_setr_epi8(0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+    // (an entry without a letter holds a value whose low nibble differs from its index: it never equals a byte that selected it)
+    const __m256i letter_lut = _mm256_setr_epi8(1, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0, 1, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i coef8 = _mm256_set1_epi16(0x0104), coef16 = _mm256_set1_epi32(0x00010010), low16 = _mm256_set1_epi64x(0xFFFF);
+    long other = 0;
+    size_t i = 0;
+    for (; i + 32 <= nbytes; i += 32) {
+        const __m256i ch = _mm256_loadu_si256((const __m256i*)(a + i));
+        const __m256i nib = _mm256_and_si256(ch, lo4), up = _mm256_and_si256(ch, upper);
+        const __m256i valid = _mm256_cmpeq_epi8(up, _mm256_shuffle_epi8(letter_lut, nib));
+        const __m256i code = _mm256_and_si256(_mm256_shuffle_epi8(code_lut, nib), valid);
+        const uint32_t inval = ~(uint32_t)_mm256_movemask_epi8(valid);
+        const uint32_t is_n = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(up, letter_n));
+        other += __builtin_popcount(inval & ~is_n);
+        const __m256i p = _mm256_maddubs_epi16(code, coef8);              // 16-bit lanes: 4 c(2j) + c(2j+1)
+        const __m256i q = _mm256_madd_epi16(p, coef16);                   // 32-bit lanes: 16 p(2k) + p(2k+1) = the byte of four bases
+        const __m256i w = _mm256_and_si256(_mm256_or_si256(_mm256_slli_epi64(q, 8), _mm256_srli_epi64(q, 32)), low16);   // 64-bit lanes: one word each
+        const size_t wi = i / 8;
+        h_codes[wi] = (uint16_t)_mm256_extract_epi64(w, 0); h_codes[wi + 1] = (uint16_t)_mm256_extract_epi64(w, 1);
+        h_codes[wi + 2] = (uint16_t)_mm256_extract_epi64(w, 2); h_codes[wi + 3] = (uint16_t)_mm256_extract_epi64(w, 3);
+        h_nmask[wi] = rev8[inval & 0xFF]; h_nmask[wi + 1] = rev8[(inval >> 8) & 0xFF];
+        h_nmask[wi + 2] = rev8[(inval >> 16) & 0xFF]; h_nmask[wi + 3] = rev8[inval >> 24];
+    }
+    return other + pack2_host_scalar(a + i, nbytes - i, h_codes + i / 8, h_nmask + i / 8);
+}
+
+long agatha_amd_pack2_host(const uint8_t* h_unpacked, size_t nbytes, uint16_t* h_codes, uint8_t* h_nmask)
+{
+    if (!h_unpacked || !h_codes || !h_nmask || (nbytes % 8) != 0) return AGATHA_AMD_EINVAL;
+    static const bool have_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
+    return have_avx2 ? pack2_host_avx2(h_unpacked, nbytes, h_codes, h_nmask) : pack2_host_scalar(h_unpacked, nbytes, h_codes, h_nmask);
 }
 
 int agatha_amd_unpack2(void* stream, const uint16_t* d_codes, const uint8_t* d_nmask, uint32_t nbytes, uint32_t* d_packed)

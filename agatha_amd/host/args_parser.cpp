@@ -5,14 +5,15 @@
 // Options are scanned over argv[1 .. argc-4]; the last two (three with -p) arguments are positional; argc < 4 is
 // refused; unknown single letters are ignored.  -b/-t are accepted and ignored by the HIP engine (its launch shape
 // is derived from the band); -c (extension) enables the reverse/complement op codes of the FASTA headers; -g N
-// (extension) spreads the host threads over N GPUs; -k (extension) packs on the host (isPacked storages, ctors.cpp:65-73);
+// (extension) spreads the host threads over N GPUs; -k (extension) packs on the host (isPacked storages, ctors.cpp:65-73),
+// -K (extension) into the 2-bit + N-mask format;
 // -S (extension) fills the start members of the results (the reference declares them and leaves them NULL).
 #include "../../include/gasal_header.h"
 
 Parameters::Parameters(int argc_, char** argv_)
     : sa(2), sb(4), gapo(4), gape(2), print_out(0), n_threads(1), slice_width(3), z_threshold(400), band_width(751),
       kernel_block_num(256), kernel_thread_num(256), kernel_align_num(8192), isPacked(false),
-      isReverseComplement(false), start_pos(0), traceback(0), n_gpus(1), argc(argc_), argv(argv_)
+      isReverseComplement(false), start_pos(0), traceback(0), n_gpus(1), isPacked2(false), argc(argc_), argv(argv_)
 {
 }
 
@@ -30,7 +31,7 @@ void Parameters::print()
     std::cerr << "kernel launch: block_num=" << kernel_block_num << ", thread_num=" << kernel_thread_num
               << ", align_num=" << kernel_align_num << std::endl;
     std::cerr << "print_out=" << print_out << " , n_threads=" << n_threads << std::endl;
-    std::cerr << std::boolalpha << "isPacked = " << isPacked << std::endl;
+    std::cerr << std::boolalpha << "isPacked = " << isPacked << ", isPacked2 = " << isPacked2 << std::endl;
     std::cerr << "query_batch_fasta_filename=" << query_batch_fasta_filename
               << " , target_batch_fasta_filename=" << target_batch_fasta_filename << std::endl;
 }
@@ -69,6 +70,7 @@ void Parameters::help()
     std::cerr << "         -n INT    number of CPU threads [" << n_threads << "]" << std::endl;
     std::cerr << "         -c        apply the reverse/complement codes of the FASTA header characters (> < / +)" << std::endl;
     std::cerr << "         -k        pack the sequences on the host and ship pre-packed batches (isPacked): half the H2D bytes" << std::endl;
+    std::cerr << "         -K        the same in the 2-bit + N-mask format (isPacked2; A, C, G, T, N only): 3/8 of the H2D bytes" << std::endl;
     std::cerr << "         -S        also compute and print the start positions (query_batch_start / target_batch_start):" << std::endl;
     std::cerr << "                   where the best alignment ENDING in the end cell begins (local-style trimming; not the first cell of the -T path," << std::endl;
     std::cerr << "                   which is the extension alignment and always starts at the origin)" << std::endl;
@@ -103,6 +105,7 @@ void Parameters::parse()
             case 'n': n_threads = next_int(c); break;
             case 'g': n_gpus = next_int(c); break;
             case 'k': isPacked = true; break;
+            case 'K': isPacked2 = true; break;
             case 'S': start_pos = 1; break;
             case 'T': traceback = 1; break;
             case 's': slice_width = next_int(c); break;

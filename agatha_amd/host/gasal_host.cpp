@@ -214,6 +214,49 @@ uint32_t gasal_host_batch_fill_packed(gasal_gpu_storage_t* s, uint32_t idx, cons
     return idx + padded;
 }
 
+// Host-side packing into the 2-bit + N-mask format (extension, params->isPacked2; the "2-bit+N-mask" option of SURVEY.md 8 f3):
+// 3 bits per base over PCIe.  A page of page_size bytes holds page_size / 3 words of eight bases: their uint16 codes in its
+// first two thirds, their mask bytes in the last third; offset and data_size count 3 bytes per word.  Letters other than
+// A, C, G, T, N (any case) have no code in this format: the call refuses them (the 4-bit formats keep them for the compare kernel).
+uint32_t gasal_host_batch_fill_packed2(gasal_gpu_storage_t* s, uint32_t idx, const char* data, uint32_t size, data_source SRC)
+{
+    host_batch_t* page; uint32_t* total;
+    pick_side(s, SRC, &page, &total);
+    const uint32_t padded = pad8(size), nw = padded / 8, need = 3 * nw, at = idx / 8 * 3;
+    while (page->is_locked) page = page->next;
+    if (page->page_size / 3 * 3 - page->data_size < need) {
+        if (!page->next) {
+            uint32_t sz = page->page_size * 2;
+            while (sz / 3 * 3 < need) sz *= 2;
+            page->next = gasal_host_batch_new(sz, page->offset + page->data_size);
+            *total += sz;
+        } else {
+            page->next->offset = page->offset + page->data_size;
+        }
+        page->is_locked = 1;
+        page = page->next;
+    }
+    const uint32_t cap_words = page->page_size / 3, wi = (at - page->offset) / 3;
+    uint16_t* codes = (uint16_t*)page->data + wi;
+    uint8_t* mask = page->data + 2 * (size_t)cap_words + wi;
+    const uint32_t whole = size & ~7u;
+    long other = agatha_amd_pack2_host((const uint8_t*)data, whole, codes, mask);
+    if (other >= 0 && padded != whole) {
+        uint8_t tail[8];
+        memset(tail, 'N', 8);
+        memcpy(tail, data + whole, size - whole);
+        const long o2 = agatha_amd_pack2_host(tail, 8, codes + whole / 8, mask + whole / 8);
+        other = o2 < 0 ? o2 : other + o2;
+    }
+    if (other < 0) CHK((int)other);
+    if (other > 0) {
+        fprintf(stderr, "[GASAL ERROR:] the 2-bit format (isPacked2) holds A, C, G, T and N only: %ld other letters in a sequence\n", other);
+        exit(EXIT_FAILURE);
+    }
+    page->data_size += need;
+    return idx + padded;
+}
+
 // Raw append without padding (host_batch.cpp:157-225)
 uint32_t gasal_host_batch_add(gasal_gpu_storage_t* s, uint32_t idx, const char* data, uint32_t size, data_source SRC)
 {
@@ -269,6 +312,7 @@ void gasal_init_streams(gasal_gpu_storage_v* vec, int max_query_len, int max_tar
         exit(EXIT_FAILURE);
     }
     const uint32_t qbytes = (uint32_t)qbytes64, tbytes = (uint32_t)tbytes64;
+    if (params->isPacked && params->isPacked2) { fprintf(stderr, "[GASAL ERROR:] isPacked and isPacked2 are two formats of the host batches: choose one\n"); exit(EXIT_FAILURE); }
     for (int i = 0; i < vec->n; i++) {
         gasal_gpu_storage_t* s = &vec->a[i];
         s->extensible_host_unpacked_query_batch = gasal_host_batch_new(qbytes, 0);
@@ -379,8 +423,8 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
     if (actual_target_batch_bytes % 8) { fprintf(stderr, "[GASAL ERROR:] actual_target_batch_bytes=%d is not a multiple of 8\n", actual_target_batch_bytes); exit(EXIT_FAILURE); }
     // (storages created with isPacked keep their pages -- and host_max_*_batch_bytes -- in PACKED bytes, gasal_host_batch_fill_packed:
     //  a batch of `actual` unpacked-equivalent bytes occupies actual / 2 of them)
-    const uint32_t host_q = params->isPacked ? actual_query_batch_bytes / 2 : actual_query_batch_bytes;
-    const uint32_t host_t = params->isPacked ? actual_target_batch_bytes / 2 : actual_target_batch_bytes;
+    const uint32_t host_q = params->isPacked2 ? actual_query_batch_bytes / 8 * 3 : params->isPacked ? actual_query_batch_bytes / 2 : actual_query_batch_bytes;
+    const uint32_t host_t = params->isPacked2 ? actual_target_batch_bytes / 8 * 3 : params->isPacked ? actual_target_batch_bytes / 2 : actual_target_batch_bytes;
     if (host_q > s->host_max_query_batch_bytes) { fprintf(stderr, "[GASAL ERROR:] actual_query_batch_bytes(%d) > host_max_query_batch_bytes(%d)\n", actual_query_batch_bytes, s->host_max_query_batch_bytes); exit(EXIT_FAILURE); }
     if (host_t > s->host_max_target_batch_bytes) { fprintf(stderr, "[GASAL ERROR:] actual_target_batch_bytes(%d) > host_max_target_batch_bytes(%d)\n", actual_target_batch_bytes, s->host_max_target_batch_bytes); exit(EXIT_FAILURE); }
     if (actual_n_alns > s->host_max_n_alns) { fprintf(stderr, "[GASAL ERROR:] actual_n_alns(%d) > host_max_n_alns(%d)\n", actual_n_alns, s->host_max_n_alns); exit(EXIT_FAILURE); }
@@ -413,12 +457,29 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
     }
 
     // H2D: every page of the two extensible host batches (gasal_align.cu:140-163)
-    for (host_batch_t* p = s->extensible_host_unpacked_query_batch; p; p = p->next)
-        CHK(agatha_amd_memcpy_h2d_async(s->str, s->unpacked_query_batch + p->offset, p->data, p->data_size));
-    for (host_batch_t* p = s->extensible_host_unpacked_target_batch; p; p = p->next)
-        CHK(agatha_amd_memcpy_h2d_async(s->str, s->unpacked_target_batch + p->offset, p->data, p->data_size));
+    if (params->isPacked2) {
+        // 2-bit + N-mask pages: the codes of all pages go to the front of the device's unpacked buffer (2 bytes per word), the mask
+        // bytes behind them (at a quarter of its size); agatha_amd_unpack2 makes the 4-bit words the kernels read
+        auto ship = [&](host_batch_t* head, uint8_t* stage, uint32_t cap_bytes, uint32_t actual_bytes, uint32_t* packed) {
+            uint8_t* d_codes = stage; uint8_t* d_mask = stage + cap_bytes / 4;
+            for (host_batch_t* p = head; p; p = p->next) {
+                const uint32_t words = p->data_size / 3, w0 = p->offset / 3, cap_words = p->page_size / 3;
+                if (!words) continue;
+                CHK(agatha_amd_memcpy_h2d_async(s->str, d_codes + 2 * (size_t)w0, p->data, 2 * (size_t)words));
+                CHK(agatha_amd_memcpy_h2d_async(s->str, d_mask + w0, p->data + 2 * (size_t)cap_words, words));
+            }
+            CHK(agatha_amd_unpack2(s->str, (const uint16_t*)d_codes, d_mask, actual_bytes, packed));
+        };
+        ship(s->extensible_host_unpacked_query_batch, s->unpacked_query_batch, s->gpu_max_query_batch_bytes & ~7u, actual_query_batch_bytes, s->packed_query_batch);
+        ship(s->extensible_host_unpacked_target_batch, s->unpacked_target_batch, s->gpu_max_target_batch_bytes & ~7u, actual_target_batch_bytes, s->packed_target_batch);
+    } else {
+        for (host_batch_t* p = s->extensible_host_unpacked_query_batch; p; p = p->next)
+            CHK(agatha_amd_memcpy_h2d_async(s->str, s->unpacked_query_batch + p->offset, p->data, p->data_size));
+        for (host_batch_t* p = s->extensible_host_unpacked_target_batch; p; p = p->next)
+            CHK(agatha_amd_memcpy_h2d_async(s->str, s->unpacked_target_batch + p->offset, p->data, p->data_size));
+    }
 
-    if (!params->isPacked) {            // gasal_align.cu:174-185
+    if (!params->isPacked && !params->isPacked2) {            // gasal_align.cu:174-185
         CHK(agatha_amd_pack(s->str, s->unpacked_query_batch, actual_query_batch_bytes, s->packed_query_batch));
         CHK(agatha_amd_pack(s->str, s->unpacked_target_batch, actual_target_batch_bytes, s->packed_target_batch));
     }
@@ -429,7 +490,7 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
     CHK(agatha_amd_memcpy_h2d_async(s->str, s->target_batch_offsets, s->host_target_batch_offsets, mb));
 
     if (params->isReverseComplement) {          // gasal_align.cu:199-213
-        if (params->isPacked) {
+        if (params->isPacked || params->isPacked2) {
             fprintf(stderr, "[GASAL ERROR:] reverse/complement ops need the unpacked batch on the device (isPacked is set)\n");
             exit(EXIT_FAILURE);
         }

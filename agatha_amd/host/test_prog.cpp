@@ -133,7 +133,10 @@ int main(int argc, char** argv)
                     if (st->current_n_alns > st->host_max_n_alns) gasal_host_alns_resize(st, st->host_max_n_alns * 2, args);
                     st->host_query_batch_offsets[j] = qidx;
                     st->host_target_batch_offsets[j] = tidx;
-                    if (args->isPacked) {       // -k: 4-bit words packed on the host, no pack kernel (ctors.cpp:65-73)
+                    if (args->isPacked2) {      // -K: 2-bit codes + N mask packed on the host, expanded on the device
+                        qidx = gasal_host_batch_fill_packed2(st, qidx, Qs.seqs[rec].c_str(), (uint32_t)Qs.seqs[rec].size(), QUERY);
+                        tidx = gasal_host_batch_fill_packed2(st, tidx, Ts.seqs[rec].c_str(), (uint32_t)Ts.seqs[rec].size(), TARGET);
+                    } else if (args->isPacked) {       // -k: 4-bit words packed on the host, no pack kernel (ctors.cpp:65-73)
                         qidx = gasal_host_batch_fill_packed(st, qidx, Qs.seqs[rec].c_str(), (uint32_t)Qs.seqs[rec].size(), QUERY);
                         tidx = gasal_host_batch_fill_packed(st, tidx, Ts.seqs[rec].c_str(), (uint32_t)Ts.seqs[rec].size(), TARGET);
                     } else {

@@ -160,6 +160,7 @@ class Parameters {
     int start_pos;                      /* extension (-S): also compute query_batch_start / target_batch_start (WITH_START, gasal.h:36) */
     int traceback;                      /* extension (-T): also compute the alignment paths (cigar / n_cigar_ops, gasal.h:91-92) */
     int n_gpus;                         /* extension (-g): host threads are spread over this many GPUs (gasal_set_device) */
+    bool isPacked2;                     /* extension (-K): host batches in the 2-bit + N-mask format (gasal_host_batch_fill_packed2): 3 bits per base over PCIe */
     std::string query_batch_fasta_filename, target_batch_fasta_filename, raw_filename;
     std::ifstream query_batch_fasta, target_batch_fasta;
     std::ofstream raw_file;
@@ -193,6 +194,10 @@ uint32_t gasal_host_batch_fill(gasal_gpu_storage_t* gpu_storage, uint32_t idx, c
  * UNPACKED layout (multiples of 8, what host_*_batch_offsets and gasal_aln_async's byte counts take), the page itself
  * holds idx / 2 bytes.  The H2D copy of such a batch is half the size and no pack kernel runs (gasal_align.cu:174). */
 uint32_t gasal_host_batch_fill_packed(gasal_gpu_storage_t* gpu_storage, uint32_t idx, const char* data, uint32_t size, data_source SRC);
+/* extension, for params->isPacked2: the same for the 2-bit + N-mask format (a uint16 of codes and a mask byte per eight bases; A, C,
+ * G, T, N only -- any other letter is refused); the page holds idx / 8 * 3 bytes, gasal_aln_async ships them and expands them on the
+ * device (agatha_amd_unpack2) instead of running the pack kernel. */
+uint32_t gasal_host_batch_fill_packed2(gasal_gpu_storage_t* gpu_storage, uint32_t idx, const char* data, uint32_t size, data_source SRC);
 uint32_t gasal_host_batch_add(gasal_gpu_storage_t* gpu_storage, uint32_t idx, const char* data, uint32_t size, data_source SRC);
 uint32_t gasal_host_batch_addbase(gasal_gpu_storage_t* gpu_storage, uint32_t idx, const char base, data_source SRC);
 void gasal_host_batch_print(host_batch_t* res);

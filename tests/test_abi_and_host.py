@@ -62,7 +62,7 @@ def test_gasal_host_library_exports_the_reference_api():
     for sym in ["gasal_copy_subst_scores", "gasal_init_gpu_storage_v", "gasal_init_streams", "gasal_host_batch_fill",
                 "gasal_host_alns_resize", "gasal_op_fill", "gasal_aln_async", "gasal_is_aln_async_done",
                 "gasal_destroy_streams", "gasal_destroy_gpu_storage_v", "gasal_set_device", "gasal_host_batch_reset",
-                "gasal_res_new_host", "Parameters::parse"]:
+                "gasal_res_new_host", "Parameters::parse", "gasal_host_batch_fill_packed(", "gasal_host_batch_fill_packed2("]:
         assert sym in out, sym
 
 

@@ -155,14 +155,18 @@ def test_reference_client_and_manual_behave_alike(tmp_path):
 def test_cli_prepacked_batches_through_the_gasal_api(tmp_path):
     """f3: `manual -k` creates its storages with isPacked (ctors.cpp:65-73), packs every sequence on the host
     (gasal_host_batch_fill_packed -> agatha_amd_pack_host) and gasal_aln_async skips the pack kernel (gasal_align.cu:174):
-    half the H2D bytes, identical score lines.  Several batches, pages that grow, lengths of every residue mod 8."""
+    half the H2D bytes, identical score lines.  Several batches, pages that grow, lengths of every residue mod 8.
+    `manual -K` does the same in the 2-bit + N-mask format (gasal_host_batch_fill_packed2 -> agatha_amd_pack2_host, expanded on
+    the device by agatha_amd_unpack2): 3/8 of the bytes, identical score lines, N runs included; other letters are refused."""
     qs, ts = synth.cfg_c4(n=400, seed=12, lo=50, hi=6000)
+    qs = synth.add_n_runs(qs, 0.1, seed=3, lo=1, hi=40)
+    ts = synth.add_n_runs(ts, 0.1, seed=4, lo=1, hi=40)
     f1, f2 = tmp_path / "ref.fasta", tmp_path / "query.fasta"
     write_fasta(f1, qs, header=">")
     write_fasta(f2, ts, header=">")
     outs = []
-    for extra in ([], ["-k"]):
-        raw = tmp_path / ("raw%d.log" % len(extra))
+    for n_extra, extra in enumerate(([], ["-k"], ["-K"])):
+        raw = tmp_path / ("raw%d.log" % n_extra)
         r = subprocess.run([MANUAL, "-p"] + extra + ["-m", "1", "-x", "4", "-q", "6", "-r", "2", "-z", "400", "-w", "751", "-a", "150",
                             str(f1), str(f2), str(raw)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -174,6 +178,14 @@ def test_cli_prepacked_batches_through_the_gasal_api(tmp_path):
     # ops + pre-packed together are refused, as documented
     r = subprocess.run([MANUAL, "-p", "-k", "-c", "-w", "100", str(f1), str(f2), str(tmp_path / "r.log")], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "isPacked" in r.stderr
+    # a letter the 2-bit format has no code for
+    qs2 = list(qs[:20]); qs2[7] = qs2[7][:10] + b"R" + qs2[7][11:]
+    f3, f4 = tmp_path / "ref2.fasta", tmp_path / "query2.fasta"
+    write_fasta(f3, qs2, header=">"); write_fasta(f4, ts[:20], header=">")
+    r = subprocess.run([MANUAL, "-p", "-K", "-w", "100", str(f3), str(f4), str(tmp_path / "r2.log")], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "2-bit format" in r.stderr
+    r = subprocess.run([MANUAL, "-p", "-k", "-w", "100", str(f3), str(f4), str(tmp_path / "r3.log")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
 
 
 def test_cli_start_positions(tmp_path):

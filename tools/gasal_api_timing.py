@@ -61,11 +61,11 @@ def time_config(qs, ts, scoring, w, z, combos=((10000, 1),), keep_dir=None):
     return out
 
 
-def time_pipeline(qs, ts, scoring, w, z, kernel_gcups=None, batch=8192, batches=16, combos=((1, False), (2, False), (4, False), (2, True), (4, True))):
+def time_pipeline(qs, ts, scoring, w, z, kernel_gcups=None, batch=8192, batches=16, combos=((1, False), (2, False), (4, False), (2, True), (4, True), (2, 2), (4, 2))):
     """The stream / batch manager over a sustained feed (wall time of {host fill, H2D, pack, sort, align, D2H},
     stream-overlapped; reference gasal_align.cu:144-162,254-266 + test_prog.cpp:273-375): `batches` batches of `batch` pairs --
     the first 2 * batch pairs of the batch at hand, run over again (AGATHA_AMD_REPEAT) -- through `manual` WITHOUT -p (production
-    mode: nothing printed, no events), 2 storages per host thread, -n 1 / 2 / 4 host threads, host ASCII and host-packed (-k).
+    mode: nothing printed, no events), 2 storages per host thread, -n 1 / 2 / 4 host threads, host ASCII, host-packed 4-bit words (-k; host_packed true) and 2-bit codes + N mask (-K; host_packed 2).
     The loop's seconds come from the CLI itself (AGATHA_AMD_LOOP_STATS; the FASTA parse is not in them).  One more run with -p
     collects the per-batch kernel times and the pairs taken over after the time-out."""
     from agatha_amd import shard
@@ -86,7 +86,7 @@ def time_pipeline(qs, ts, scoring, w, z, kernel_gcups=None, batch=8192, batches=
             stats = os.path.join(d, "loop.txt")
             if os.path.exists(stats):
                 os.remove(stats)
-            cmd = [MANUAL] + (["-k"] if packed else []) + base + ["-n", str(n_threads), ref_fa, query_fa]
+            cmd = [MANUAL] + (["-K"] if packed == 2 else ["-k"] if packed else []) + base + ["-n", str(n_threads), ref_fa, query_fa]
             env = dict(os.environ, AGATHA_AMD_REPEAT=str(rep), AGATHA_AMD_LOOP_STATS=stats)
             t0 = time.time()
             subprocess.check_call(cmd, stdout=subprocess.DEVNULL, env=env)
