@@ -45,7 +45,7 @@ DebugOption g_opts[] = {
     {"force_split", "AGATHA_AMD_FORCE_SPLIT", {0}},    // > 0: this many pairs (the longest) on the latency shape beside the throughput shape, whatever the cost model says (tests)
     {"ck_newer", "AGATHA_AMD_CK_NEWER", {1}},          // int16 kernel, three register pairs per lane: 1 = a pair that must go back takes the newer of its two checkpoints when the bound of its maximum has risen far enough behind it, 0 = always the older one (round 3)
     {"ck_shift", "AGATHA_AMD_CK_SHIFT", {28}},         // int16 kernel: a pair of s steps takes a checkpoint every 2^(n - clz(s)) steps (28: every eighth to sixteenth of the pair, 29: quarter to eighth)
-    {"lat_blocks", "AGATHA_AMD_LAT_BLOCKS", {0}},      // > 0: a batch split by length keeps its long pairs on this many workgroups of the latency shape (experiments; 0: the model's choice)
+    {"lat_blocks", "AGATHA_AMD_LAT_BLOCKS", {0}},      // > 0: a batch split by length keeps its long pairs on this many workgroups of the latency shape (experiments; 0: no cap)
     {"no_split", "AGATHA_AMD_NO_SPLIT", {0}},          // 1: a batch of mixed lengths is never split between the two int16 shapes (one shape per launch, as before round 4)
     {"prio_fine", "AGATHA_AMD_PRIO_FINE", {0}},        // quarters of a slice added to slot 0's share of the issue priority (static schedule)
     {"fast_margin", "AGATHA_AMD_FAST_MARGIN", {12}},   // int16 kernel: value steps except in a window of key steps at a pair's end that starts n + steps / 128 before the corner of the shorter sequence; 0: key steps only

@@ -31,7 +31,7 @@ struct AlignLaunch {
     int force_split;               // > 0: split the batch between the two int16 shapes with this many pairs on the latency shape, whatever the model says (tests, fuzzers)
     int ck_newer;                  // int16 kernel, shapes without checkpoint bookkeeping: 1 = a pair goes back to the newer of its two checkpoints when its bound has risen enough behind it (debug option ck_newer)
     int ck_shift;                  // int16 kernel: 2^(ck_shift - clz(steps of the pair)) steps between two checkpoints (debug option ck_shift)
-    int lat_blocks;                // > 0: workgroups of the latency shape that take the long pairs of a split batch (debug option; 0: queue[12], the model's choice)
+    int lat_blocks;                // > 0: workgroups of the latency shape that take the long pairs of a split batch (debug option lat_blocks, experiments; 0: no cap)
     float* totals;                 // device: [0] sum of steps over the batch, [1] steps of the longest pair (sort_scan_kernel)
     unsigned int* kind_counts;     // device: [0] pairs of kind 1, [1] pairs of kind 2 (kernels with nothing to do return at once)
     int force_cmp;                 // 1 = scores do not fit the byte profile: compare path for every pair
