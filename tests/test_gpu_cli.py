@@ -326,12 +326,12 @@ def test_cli_start_positions_of_ultra_long_reads(tmp_path):
     assert exp[0, 0] > 100000
 
 
-@pytest.mark.parametrize("threads,packed", [(1, False), (2, True)])
+@pytest.mark.parametrize("threads,packed", [(1, False), (2, True), (2, 2)])
 def test_cli_sustained_feed_of_sixteen_batches(tmp_path, threads, packed):
     """The stream / batch manager behind gasal_aln_async over a sustained feed ({host fill, H2D, pack, sort, align,
     D2H} stream-overlapped; reference gasal_align.cu:144-162,254-266 + test_prog.cpp:273-375): the pairs of the two files run eight
-    times over (AGATHA_AMD_REPEAT), sixteen batches of 9 000 pairs through two storages per host thread, host ASCII and host-packed
-    (-k).  Every batch prints the oracle's lines; no batch shows a pair taken over after the 50 ms time-out (each batch is a
+    times over (AGATHA_AMD_REPEAT), sixteen batches of 9 000 pairs through two storages per host thread, host ASCII, host-packed
+    (-k) and in the 2-bit + N-mask format (-K; packed = 2).  Every batch prints the oracle's lines; no batch shows a pair taken over after the 50 ms time-out (each batch is a
     persistent full-chip grid on a static schedule enqueued behind the other storage's); the CLI reports the seconds of its batch
     loop (AGATHA_AMD_LOOP_STATS), which is what bench.py's `gasal_api.pipeline` turns into end-to-end GCUPS."""
     a, rep = 9000, 8
@@ -342,7 +342,7 @@ def test_cli_sustained_feed_of_sixteen_batches(tmp_path, threads, packed):
     write_fasta(f2, ts, header=">", width=10 ** 9)
     P = O.make_params(w=200, z=100)
     exp = np.stack(O.align_pairs(qs, ts, P, wide=True, threads=8), axis=1)
-    cmd = [MANUAL] + (["-k"] if packed else []) + ["-p", "-w", "200", "-z", "100", "-a", str(a), "-n", str(threads), str(f1), str(f2), str(raw)]
+    cmd = [MANUAL] + (["-K"] if packed == 2 else ["-k"] if packed else []) + ["-p", "-w", "200", "-z", "100", "-a", str(a), "-n", str(threads), str(f1), str(f2), str(raw)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, AGATHA_AMD_RAW_STATS=str(stats), AGATHA_AMD_LOOP_STATS=str(loop), AGATHA_AMD_REPEAT=str(rep),
                                 AGATHA_AMD_FORCE_INT16="1"))
