@@ -205,6 +205,43 @@ def test_c1_with_broken_pairs_on_the_static_schedule(eng):
     assert np.mean((got[1] + got[2] + 2 < 0.95 * (ql + tl))[broken]) > 0.7          # they did end early
 
 
+def test_c1_with_many_broken_pairs_goes_back_to_checkpoints_not_to_first_steps(eng):
+    """30 % of 10 000 C1 reads have an unrelated tail (tools/gpu_skew.py's hardest batch): thousands of pairs go back to a checkpoint,
+    many of them after the schedule has moved them to another lane group.  Round 4: a pair goes back to the NEWER of its two
+    checkpoints when the bound it keeps of its maximum allows it (debug option ck_newer), and a pair that is resumed on key steps by a
+    wave on value steps keeps its exact keys -- before, such a pair started over from its first step far into its steps.  Asserted:
+    every broken pair and 300 others equal the oracle; the whole batch is the same with ck_newer = 0; few pairs start over from their
+    first step (they do so only within their first checkpoint spans) and the key steps stay a fraction of the value steps."""
+    import agatha_amd
+    qs, ts = synth.cfg_c1(n=10000)
+    rng = np.random.default_rng(5)
+    ts = list(ts)
+    broken = []
+    for i in range(10000):
+        if rng.random() < 0.3:
+            a = np.frombuffer(ts[i], np.uint8).copy()
+            h = int(rng.integers(len(a) // 10, len(a)))
+            a[h:] = synth.random_seq(rng, len(a) - h)
+            ts[i] = a.tobytes()
+            broken.append(i)
+    broken = np.array(broken)
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
+    batch, got, (choice, sched, st, kinds) = _run_batch(eng, qs, ts, **p)
+    assert choice == ("int16", 16, 6) and sched[0]
+    assert st[15] > 2000 and st[24] == 0 and kinds[2] == 0
+    assert st[2] < 200 and st[1] < st[0] // 4, (st[2], st[1], st[0])
+    others = np.setdiff1d(np.random.default_rng(9).choice(10000, 300, replace=False), broken)
+    _sampled_check((qs, ts), got, np.sort(np.concatenate([broken, others])), p)
+    old = agatha_amd.get_debug_option("ck_newer")
+    agatha_amd.set_debug_option("ck_newer", 0)
+    try:
+        _, got0, (_, _, st0, _) = _run_batch(eng, qs, ts, **p)
+    finally:
+        agatha_amd.set_debug_option("ck_newer", old)
+    assert all(np.array_equal(a, b) for a, b in zip(got, got0))
+    assert st0[15] > 2000
+
+
 def test_a_few_long_pairs_among_many_short_ones_are_split_between_the_two_int16_shapes(eng):
     """Round 4 (the purpose of the reference's uneven bucketing, agatha_kernel.h:113, and subwarp rejoining, :365-408, re-derived
     for a batch of mixed lengths): 20 000 bundled-dataset-like pairs with 12 pairs of 30 kb among them.  One shape per launch puts
