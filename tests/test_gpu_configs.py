@@ -205,6 +205,22 @@ def test_c1_with_broken_pairs_on_the_static_schedule(eng):
     assert np.mean((got[1] + got[2] + 2 < 0.95 * (ql + tl))[broken]) > 0.7          # they did end early
 
 
+def test_targets_shorter_than_their_queries_by_more_than_the_band_stay_on_the_int16_kernel(eng):
+    """HiFi-like pairs (band 500: cut diagonal -4) whose target is cut to 90 %: the band leaves the matrix through the last column a
+    few hundred rows below the target's end, and the last block of the column holds only padded columns -- cells that derive from the
+    reference's -infinity (agatha_kernel.h:207-215).  An anti-diagonal with nothing else on it used to trip the int16 kernel's range
+    check (1 163 of 9 000 such pairs went to the int32 kernel: 65 instead of 31 ms); it now ends the pair, whose result is final.
+    Asserted: no pair is abandoned, 300 pairs equal the oracle; the same with the QUERIES cut."""
+    qs, ts = synth.cfg_c2(n=3000)
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=500)
+    for cut_targets in (True, False):
+        q2 = [q if cut_targets else q[:int(len(q) * 0.9)] for q in qs]
+        t2 = [t[:int(len(t) * 0.9)] if cut_targets else t for t in ts]
+        batch, got, (choice, sched, st, kinds) = _run_batch(eng, q2, t2, **p)
+        assert choice[0] == "int16" and kinds[2] == 0 and st[24] == 0, (choice, kinds)
+        _sampled_check((q2, t2), got, np.sort(np.random.default_rng(4).choice(3000, 300, replace=False)), p)
+
+
 def test_c1_with_many_broken_pairs_goes_back_to_checkpoints_not_to_first_steps(eng):
     """30 % of 10 000 C1 reads have an unrelated tail (tools/gpu_skew.py's hardest batch): thousands of pairs go back to a checkpoint,
     many of them after the schedule has moved them to another lane group.  Round 4: a pair goes back to the NEWER of its two

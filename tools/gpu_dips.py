@@ -10,8 +10,10 @@ share = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
 import os
 RANDOM = os.environ.get("DIPS_RANDOM") == "1"          # the burst is unrelated sequence instead of a 40 % error stretch
 eng = agatha_amd.Engine(0)
-sc = agatha_amd.Scores.make()
-qs0, ts0 = W.cfg_c1(n=n)
+import os
+CFG = os.environ.get("CFG", "cfg_c1")          # (CFG=cfg_c2 BAND=500: the HiFi shape, two register pairs per lane, checkpoints with bookkeeping)
+sc = agatha_amd.Scores.make(w=int(os.environ.get("BAND", "751")))
+qs0, ts0 = getattr(W, CFG)(n=n)
 for burst in ([int(sys.argv[3])] if len(sys.argv) > 3 and sys.argv[3].isdigit() else ([0, 60, 100, 140, 180, 0] if RANDOM else [0, 150, 250, 350, 500, 0])):
     rng = np.random.default_rng(11)
     ts = []

@@ -8,8 +8,10 @@ import agatha_amd
 from agatha_amd import workload as W
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10000
 eng = agatha_amd.Engine(0)
-sc = agatha_amd.Scores.make()
-qs0, ts0 = W.cfg_c1(n=n)
+import os
+CFG = os.environ.get("CFG", "cfg_c1")          # (CFG=cfg_c2 BAND=500: the HiFi shape, two register pairs per lane, checkpoints with bookkeeping)
+sc = agatha_amd.Scores.make(w=int(os.environ.get("BAND", "751")))
+qs0, ts0 = getattr(W, CFG)(n=n)
 rng = np.random.default_rng(5)
 for name, fq, ft in (("equal", 1.0, 1.0), ("target 90 %", 1.0, 0.9), ("target 75 %", 1.0, 0.75), ("query 90 %", 0.9, 1.0), ("query 75 %", 0.75, 1.0),
                      ("1 % broken", -0.01, 1.0), ("5 % broken", -0.05, 1.0), ("30 % broken", -0.3, 1.0)):
@@ -30,7 +32,7 @@ for name, fq, ft in (("equal", 1.0, 1.0), ("target 90 %", 1.0, 0.9), ("target 75
     for _ in range(3):
         e0, e1 = eng.event(), eng.event(); eng.record(e0); b.align(sc); eng.record(e1); ms.append(eng.elapsed_ms(e0, e1))
     st = b.step_stats()
-    cells = W.nominal_cells_total(ql, tl, 751)
+    cells = W.nominal_cells_total(ql, tl, int(os.environ.get("BAND", "751")))
     print(f"{name:12s} align {min(ms):7.2f} ms  {cells / min(ms) / 1e6:7.1f} GCUPS  value steps {st[0]} key steps {st[1]} started over {st[2]} back to checkpoint {st[15]} "
           f"to int32 {st[24]} ended without the cell {st[6]} not calm on values {st[4]} key step without the cell {st[5]} back by n x 256 steps {st[16:24]} started over at n x 512 steps {st[25:33]} why (second time, no checkpoints, c0 < span, c0 <= first, slot invalid) {st[33:38]} suspended with an older checkpoint {st[38]}")
     if "--timeline" in sys.argv:
