@@ -51,7 +51,7 @@ DebugOption g_opts[] = {
     {"fast_margin", "AGATHA_AMD_FAST_MARGIN", {12}},   // int16 kernel: value steps except in a window of key steps at a pair's end that starts n + steps / 128 before the corner of the shorter sequence; 0: key steps only
     {"fast_anchor", "AGATHA_AMD_FAST_ANCHOR", {1}},   // int16 kernel: 1 = the window of key steps is anchored at the corner of the shorter sequence, 0 = at the pair's last step (experiments)
     {"static_ck", "AGATHA_AMD_STATIC_CK", {1}},   // int16 kernel, static schedule, three register pairs per lane: 1 = checkpoints there as well (a pair that must be started over goes back in place), 0 = none (such a pair goes to the int32 kernel behind)
-    {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {1024}},   // int16 kernel: pairs of at least this many steps take checkpoints (0: none do)
+    {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {384}},    // int16 kernel: pairs of at least this many steps take checkpoints (0: none do; 1024 until late in round 4: 3 kb pairs with broken reads among them, 22 -> 19 ms)
 };
 enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;

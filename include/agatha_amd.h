@@ -64,7 +64,7 @@ int agatha_amd_max_band(void);
  * larger batches add ~136 MiB for the pairs that are suspended and resumed by another lane group when the batch is larger
  * than one round of lane groups -- a caller that passes less gets the work queue instead, never an error) */
 size_t agatha_amd_workspace_bytes(uint32_t max_n_alns);
-/* The same plus, when the sequences can be long (ceil(query / 8) + ceil(target / 8) >= 1024 -- the debug option ck_min_steps --, or a length given as 0 =
+/* The same plus, when the sequences can be long (ceil(query / 8) + ceil(target / 8) >= 384 -- the debug option ck_min_steps --, or a length given as 0 =
  * unknown), the checkpoint area of the packed-int16 kernel: two slots of ~8-58 KiB per lane group in flight (at most
  * ~200 MiB), where a long pair's state is saved every eighth of its steps.  A long pair that must be started over -- z-drop
  * came into reach on a step that only tracked the maxima's values -- then goes back one checkpoint instead of to its first
