@@ -534,6 +534,11 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
             if (v == INT_MIN || (v >> K) < L16_GLO) { H = -32768; c = 0; }      /* empty, or only out-of-band cells */
             else {
                 H = (v >> K) + base - ge * d; c = (v & KMASK) + cb;
+                /* (round 4) only cells that derive from -infinity are left on this anti-diagonal (padded columns behind a short target's
+                 * end, rows behind the band's last block): no real anti-diagonal maximum falls from the in-band zone to below L16_LO in
+                 * one anti-diagonal, and nothing real follows one that has: the result is final, the pair ends here (align16_body.inc) */
+                if ((v >> K) < L16_LO && pos_known && !stale) { stopped = 1; H = -32768; c = 0; }
+                else
                 if ((v >> K) < L16_LO + spread + L16_DELTA || H < NEG_INF2 + spread) { bail = 1; break; }
             }
             if (H > best) { best = H; best_t = c; best_q = d - c; pos_known = !stale; }

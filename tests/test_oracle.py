@@ -228,6 +228,32 @@ def _py_transform(seq, op, pad_first):
     return s.translate(comp) if op & 2 else s
 
 
+def test_int16_model_ends_a_pair_whose_real_cells_have_run_out():
+    """A target (or query) shorter than the other sequence by more than the band: the band leaves the matrix through the last column
+    (row) and the blocks behind it hold only padded columns, cells that derive from the reference's -infinity (agatha_kernel.h:207-215).
+    The int16 kernel ends such a pair on the first anti-diagonal whose maximum lies below its in-band zone -- the result is final --
+    instead of abandoning it to the int32 kernel (align16_body.inc, round 4); its arithmetic model does the same here: no pair bails
+    out, every result is the oracle's, at bands whose cut diagonal differs, with and without z-drop."""
+    rng = np.random.default_rng(3)
+    for w in (20, 47, 133):
+        for cut, side in ((0.5, 0), (0.9, 0), (0.8, 1)):
+            qs, ts = synth.make_pairs(int(rng.integers(1, 10 ** 6)), 12, lambda r: int(r.integers(600, 2000)), 0.03, 0.03, 0.04)
+            if side == 0:
+                ts = [t[:max(8, int(len(t) * cut))] for t in ts]
+            else:
+                qs = [q[:max(8, int(len(q) * cut))] for q in qs]
+            qb, qo, ql = O.make_batch(qs)
+            tb, to, tl = O.make_batch(ts)
+            W = (w + 7) // 8
+            G, S = [c for c in ((16, 2), (16, 4), (16, 6)) if c[0] * c[1] >= W + 1][0]
+            for z in (400, -1):
+                prm = O.make_params(2, 4, 4, 2, 3, z, w)
+                e = O.align_batch(qb, tb, qo, to, ql, tl, prm, wide=True, model=O.MODEL_STEPS, threads=4)
+                sc, qe, te, kind, st = O.lanes16_batch(qb, tb, qo, to, ql, tl, prm, G, S, threads=4)
+                assert (kind == 0).all(), (w, cut, side, z, kind)
+                assert np.array_equal(e[0], sc) and np.array_equal(e[1], qe) and np.array_equal(e[2], te), (w, cut, side, z)
+
+
 def test_seq_ops_reference_as_written_and_product_semantics():
     """f2 (reverse / complement op path): oracle/seq_ops_ref.c restates the reference's gasal_reversecomplement_kernel
     (pack_rc_seqs.h:56-212) as written and the semantics the product implements.  Pinned here: (1) the restatement
