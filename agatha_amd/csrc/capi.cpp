@@ -43,7 +43,7 @@ DebugOption g_opts[] = {
     {"prio_duty", "AGATHA_AMD_PRIO_DUTY", {0}},        // slices out of 16 in which the wave in slot 0 of its SIMD is favoured; 0 = automatic (8, or by the waves' step counts); -1: also no priority by the length of a wave's pair on the latency shapes' work queue
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
     {"force_split", "AGATHA_AMD_FORCE_SPLIT", {0}},    // > 0: this many pairs (the longest) on the latency shape beside the throughput shape, whatever the cost model says (tests)
-    {"ck_newer", "AGATHA_AMD_CK_NEWER", {1}},          // int16 kernel, three register pairs per lane: 1 = a pair that must go back takes the newer of its two checkpoints when the bound of its maximum has risen far enough behind it, 0 = always the older one (round 3)
+    {"ck_newer", "AGATHA_AMD_CK_NEWER", {1}},          // int16 kernel: 1 = a pair that must go back takes the newer of its two checkpoints when the bound of its maximum has risen far enough behind it (three register pairs per lane) / the checkpoint before "keep" when it has hardly risen behind "keep" (one or two), 0 = always the older one / always "keep" (round 3)
     {"ck_shift", "AGATHA_AMD_CK_SHIFT", {28}},         // int16 kernel: a pair of s steps takes a checkpoint every 2^(n - clz(s)) steps (28: every eighth to sixteenth of the pair, 29: quarter to eighth)
     {"lat_blocks", "AGATHA_AMD_LAT_BLOCKS", {0}},      // > 0: a batch split by length keeps its long pairs on this many workgroups of the latency shape (experiments; 0: no cap)
     {"no_split", "AGATHA_AMD_NO_SPLIT", {0}},          // 1: a batch of mixed lengths is never split between the two int16 shapes (one shape per launch, as before round 4)

@@ -29,7 +29,7 @@ struct AlignLaunch {
     int* choice;                   // device: index of the candidate that takes the kind-0 pairs
     int force_choice;              // >= 0: candidate index to use regardless of the model (AGATHA_AMD_FORCE_CHOICE, experiments)
     int force_split;               // > 0: split the batch between the two int16 shapes with this many pairs on the latency shape, whatever the model says (tests, fuzzers)
-    int ck_newer;                  // int16 kernel, shapes without checkpoint bookkeeping: 1 = a pair goes back to the newer of its two checkpoints when its bound has risen enough behind it (debug option ck_newer)
+    int ck_newer;                  // int16 kernel: 1 = a pair goes back to the newer of its two checkpoints when its bound has risen enough behind it (shapes without bookkeeping), to the checkpoint before "keep" when it has not (shapes with it); 0 = round 3's rule (debug option ck_newer)
     int ck_shift;                  // int16 kernel: 2^(ck_shift - clz(steps of the pair)) steps between two checkpoints (debug option ck_shift)
     int lat_blocks;                // > 0: workgroups of the latency shape that take the long pairs of a split batch (debug option lat_blocks, experiments; 0: no cap)
     float* totals;                 // device: [0] sum of steps over the batch, [1] steps of the longest pair (sort_scan_kernel)
