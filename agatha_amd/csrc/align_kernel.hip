@@ -546,6 +546,51 @@ schedule_kernel(AlignLaunch L, int GS, int G)
     __syncthreads();
     uint32_t acc = part[t];
     for (int j = j0; j < j1; j++) { L.cum[j] = acc; acc += steps_of(j); }
+    // ---- which physical lane group owns which interval (round 5) ----
+    // A wave runs key steps while ANY of its lane groups' pairs is in the window at its end (align16_body.inc, want_keys), so a wave
+    // whose four intervals end their pairs at four different times runs four windows.  Every interval ends with the rest of the
+    // pair that crosses out of it (at step T, the same for all); what differs is where a WHOLE pair ends inside an interval --
+    // about one interval in five has one (n pairs on m > n / 2 groups).  The intervals are sorted by the step at which their first
+    // whole pair ends (T: none does), and consecutive intervals of that order go to the lane groups of one wave, consecutive waves
+    // to one CU (workgroups b and b + half share a CU on a full persistent grid): the windows of a wave, and of the waves that share
+    // an instruction cache, then coincide.  Counting sort over 2048 bins of the step, one workgroup.
+    if (L.mig_perm == nullptr) return;
+    __shared__ uint32_t bins[2048];
+    __threadfence_block();
+    __syncthreads();
+    const int T_ = L.sched[1];
+    const bool use_ = L.sched[0] != 0 && T_ > 0 && !L.mig_identity;
+    for (int b = t; b < 2048; b += 1024) bins[b] = 0u;
+    __syncthreads();
+    auto end_key = [&](int g) -> uint32_t {
+        // first pair that reaches beyond the start of the interval (the kernel's own search), then the first one that lies whole inside
+        const uint32_t lo = (uint32_t)g * (uint32_t)T_, hi = lo + (uint32_t)T_;
+        int a = 0, b = n;
+        while (a < b) { const int mid = (a + b) >> 1; if (L.cum[mid + 1] > lo) b = mid; else a = mid + 1; }
+        for (int j = a; j < n && L.cum[j] < hi; j++) {
+            const uint32_t c = L.cum[j], c1 = L.cum[j + 1];
+            if (c1 == c || c < lo) continue;
+            if (c1 <= hi) return c1 - lo;           // a whole pair: it ends c1 - lo steps into the interval
+            break;
+        }
+        return (uint32_t)T_;
+    };
+    auto bin_of = [&](uint32_t key) -> uint32_t { return (uint32_t)(((unsigned long long)key * 2047ull) / (unsigned long long)T_); };
+    if (use_) {
+        for (int g = t; g < m; g += 1024) atomicAdd(&bins[bin_of(end_key(g))], 1u);
+    }
+    __syncthreads();
+    if (t == 0 && use_) { uint32_t a = 0; for (int b = 0; b < 2048; b++) { const uint32_t v = bins[b]; bins[b] = a; a += v; } }
+    __syncthreads();
+    const int gpb = m / (2 * L.num_cus) > 0 ? m / (2 * L.num_cus) : 1, half = L.num_cus;     // lane groups per workgroup; workgroups per half of the grid
+    for (int g = t; g < m; g += 1024) {
+        if (!use_ || m != 2 * L.num_cus * gpb) { L.mig_perm[g] = g; continue; }
+        const uint32_t u = atomicAdd(&bins[bin_of(end_key(g))], 1u);       // rank of interval g in the sorted order
+        // rank u -> physical lane group: CU u / (2 gpb), its first workgroup for the first gpb ranks, its second for the rest
+        const int cu = (int)(u / (uint32_t)(2 * gpb)), within = (int)(u % (uint32_t)(2 * gpb));
+        const int blk = within < gpb ? cu : cu + half;
+        L.mig_perm[blk * gpb + within % gpb] = g;
+    }
 }
 
 hipError_t launch_schedule(const AlignLaunch& L, hipStream_t st)

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <mutex>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -51,9 +52,12 @@ DebugOption g_opts[] = {
     {"fast_margin", "AGATHA_AMD_FAST_MARGIN", {12}},   // int16 kernel: value steps except in a window of key steps at a pair's end that starts n + steps / 128 before the corner of the shorter sequence; 0: key steps only
     {"fast_anchor", "AGATHA_AMD_FAST_ANCHOR", {1}},   // int16 kernel: 1 = the window of key steps is anchored at the corner of the shorter sequence, 0 = at the pair's last step (experiments)
     {"static_ck", "AGATHA_AMD_STATIC_CK", {1}},   // int16 kernel, static schedule, three register pairs per lane: 1 = checkpoints there as well (a pair that must be started over goes back in place), 0 = none (such a pair goes to the int32 kernel behind)
+    {"win_cap_min", "AGATHA_AMD_WIN_CAP_MIN", {128}},    // int16 kernel: the adaptive part of the window of key steps at a pair's end is capped at max(win_cap_min, steps of the pair / win_cap_div)
+    {"win_cap_div", "AGATHA_AMD_WIN_CAP_DIV", {16}},
+    {"mig_identity", "AGATHA_AMD_MIG_IDENTITY", {0}},   // static schedule: 1 = lane group g owns interval g of the line of pairs (until round 4); 0 = intervals whose pairs end together share a wave (schedule_kernel)
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {384}},    // int16 kernel: pairs of at least this many steps take checkpoints (0: none do; 1024 until late in round 4: 3 kb pairs with broken reads among them, 22 -> 19 ms)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_CK_MIN_STEPS, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -85,24 +89,39 @@ int num_cus()
 // agatha_amd_stream_create get theirs there (the GASAL layer's: nothing is created inside a timed batch); a foreign stream
 // (torch's, the null stream) gets one at its first call.  Kept until agatha_amd_stream_destroy / for the life of the process.
 struct AuxStream { hipStream_t s; hipEvent_t fork, join; };
+// (keyed by device AND stream: the null stream -- torch's default stream too -- is the same handle on every device, and an event or a
+//  stream of one device must never be used on another: a process that drives several GPUs gets one entry per device.  Two host threads
+//  that align on the SAME stream at the same time would share one fork / join pair; HIP streams are not meant to be fed by two threads
+//  at once without the caller's own ordering, and the header says so: one caller per stream.)
+struct AuxKey { int dev; void* stream; bool operator==(const AuxKey& o) const { return dev == o.dev && stream == o.stream; } };
+struct AuxKeyHash { size_t operator()(const AuxKey& k) const { return std::hash<void*>()(k.stream) ^ ((size_t)(unsigned)k.dev * 0x9E3779B97F4A7C15ull); } };
 std::mutex g_aux_mutex;
-std::unordered_map<void*, AuxStream> g_aux;
+std::unordered_map<AuxKey, AuxStream, AuxKeyHash> g_aux;
+int current_device() { int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; } return dev; }
 AuxStream* aux_stream(void* main_stream)
 {
+    const AuxKey key{current_device(), main_stream};
     std::lock_guard<std::mutex> lock(g_aux_mutex);
-    auto it = g_aux.find(main_stream);
+    auto it = g_aux.find(key);
     if (it != g_aux.end()) return &it->second;
-    AuxStream a;
-    if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError(); return nullptr;
+    AuxStream a{nullptr, nullptr, nullptr};
+    bool ok = hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&a.join, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {          // nothing half-made is kept: the caller runs everything on its own stream instead
+        (void)hipGetLastError();
+        if (a.join) (void)hipEventDestroy(a.join);
+        if (a.fork) (void)hipEventDestroy(a.fork);
+        if (a.s) (void)hipStreamDestroy(a.s);
+        return nullptr;
     }
-    return &g_aux.emplace(main_stream, a).first->second;
+    return &g_aux.emplace(key, a).first->second;
 }
 void aux_stream_drop(void* main_stream)
 {
+    const AuxKey key{current_device(), main_stream};
     std::lock_guard<std::mutex> lock(g_aux_mutex);
-    auto it = g_aux.find(main_stream);
+    auto it = g_aux.find(key);
     if (it == g_aux.end()) return;
     (void)hipStreamDestroy(it->second.s); (void)hipEventDestroy(it->second.fork); (void)hipEventDestroy(it->second.join);
     g_aux.erase(it);
@@ -118,7 +137,7 @@ size_t base_workspace_bytes(uint32_t n)
 }
 size_t mig_workspace_bytes(uint32_t n)
 {
-    return round_up(sizeof(uint32_t) * ((size_t)n + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) +
+    return round_up(sizeof(uint32_t) * ((size_t)n + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots) +
            round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords) + agatha::kMigBufBytes;
 }
 
@@ -369,6 +388,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
                      opt(OPT_NO_MIGRATE) <= 0;
     uint32_t* cum = (uint32_t*)ws;                           ws += round_up(sizeof(uint32_t) * ((size_t)n_alns + 1));
     int* mig_state = (int*)ws;                               ws += round_up(sizeof(int) * (agatha::kMigMaxSlots + 1));
+    int* mig_perm = (int*)ws;                                ws += round_up(sizeof(int) * agatha::kMigMaxSlots);
     uint32_t* timeline = (uint32_t*)ws;                      ws += round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords);
     uint32_t* mig_buf = (uint32_t*)ws;
     // the checkpoint area lies behind everything else (behind the schedule's areas when the workspace holds them)
@@ -422,7 +442,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         HIPCHK(agatha::launch_tb_plan(L, tb_gs, (unsigned long long)(cap / 4), tb_passes, off, pass, plan, st));
     }
     L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;
-    L.mig_slot_dwords = 0; L.mig_fallback = 0;
+    L.mig_slot_dwords = 0; L.mig_fallback = 0; L.mig_perm = nullptr; L.mig_identity = opt(OPT_MIG_IDENTITY) ? 1 : 0;
     L.timeline = nullptr;
     L.simd_steps = simd_steps;
     HIPCHK(hipMemsetAsync(simd_steps, 0, sizeof(int) * agatha::kSimdStepsInts, st));
@@ -437,6 +457,16 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.mig_fresh_timeout_ticks = 100u * (unsigned)std::max(std::min(opt(OPT_MIG_FRESH_TIMEOUT_US), opt(OPT_MIG_TIMEOUT_US)), 0);
     L.mig_test_delay_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TEST_DELAY_US), 0);
     L.fast_margin = std::max(opt(OPT_FAST_MARGIN), 0);
+    L.win_cap_min = std::max(opt(OPT_WIN_CAP_MIN), 0); L.win_cap_div = std::max(opt(OPT_WIN_CAP_DIV), 1);
+    {
+        // the window of key steps a pair starts with, before it has shown its own rate of rise (align16_body.inc, widen_window): the steps a
+        // read with 15 % errors needs to rise by more than the slack of a value step's bound, 3.5 sigma
+        const double m_ = sc->match, pen = std::max<double>(sc->match + sc->mismatch, 0.5 * sc->match + sc->gap_open + sc->gap_extend), e0 = 0.15;
+        const double X = 7.0 * std::max(sc->mismatch, 1) + 7.0 * sc->gap_extend, mu = 4.0 * (m_ - e0 * pen), V = 4.0 * e0 * pen * pen, k2 = 12.0;
+        double n = 4096.0;
+        if (mu > 0.0) { const double r = (std::sqrt(k2 * V) + std::sqrt(k2 * V + 4.0 * mu * X)) / (2.0 * mu); n = std::min(4096.0, r * r); }
+        L.win_prior = (int)std::ceil(n);
+    }
     L.ck_buf = have_ck ? (uint32_t*)((char*)d_workspace + ck_off) : nullptr;
     // (what the caller's workspace really holds behind ck_off: the kernel derives from it how many of ITS lane groups fit -- a grid
     //  made larger than the default with the max_blocks debug option must not write checkpoints past the end of the workspace)
@@ -465,7 +495,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         if (slots <= agatha::kMigMaxSlots && (size_t)slots * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes) {
             // (room for a second state per boundary: the fallback of a pair that is suspended with a bound for its maximum)
             const bool two = (size_t)slots * 2 * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes;
-            L.mig_enabled = opt(OPT_NO_MIGRATE) < 0 ? 2 : 1; L.mig_slots = slots; L.mig_slot_dwords = two ? 2 * dwords : dwords; L.mig_fallback = two ? 1 : 0;
+            L.mig_enabled = opt(OPT_NO_MIGRATE) < 0 ? 2 : 1; L.mig_slots = slots; L.mig_perm = mig_perm; L.mig_slot_dwords = two ? 2 * dwords : dwords; L.mig_fallback = two ? 1 : 0;
             HIPCHK(hipMemsetAsync(mig_state, 0, sizeof(int) * ((size_t)slots + 1), st));
             HIPCHK(agatha::launch_schedule(L, st));
         }
@@ -667,7 +697,7 @@ int agatha_amd_timeline(void* stream, const void* d_workspace, uint32_t n_alns, 
     // the timeline area is part of the schedule's areas: only workspaces sized for more than kMigMinPairs pairs have it
     if (n_alns <= kMigMinPairs) { snprintf(g_err, sizeof(g_err), "agatha_amd_timeline: workspaces for <= %u pairs hold no timeline area", kMigMinPairs); return AGATHA_AMD_EWORKSPACE; }
     const char* ws = (const char*)d_workspace;
-    ws += base_workspace_bytes(n_alns) + round_up(sizeof(uint32_t) * ((size_t)n_alns + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1));
+    ws += base_workspace_bytes(n_alns) + round_up(sizeof(uint32_t) * ((size_t)n_alns + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots);
     const uint32_t nw = std::min<uint32_t>(max_waves, agatha::kTimelineWaves);
     hipError_t e = hipMemcpyAsync(out, ws, sizeof(uint32_t) * agatha::kTimelineDwords * nw, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);

@@ -48,8 +48,10 @@ struct AlignLaunch {
     uint32_t* cum;                 // device: [n + 1] exclusive prefix sums of the pairs' step counts in sorted order
     int* sched;                    // device: [0] 1 = static schedule in force, [1] T = steps per lane group, [2] groups used
     int* mig_state;                // device: [mig_slots + 1] state of the pair that crosses each group boundary
+    int* mig_perm;                 // device: [mig_slots] the interval of the line of pairs each physical lane group owns (schedule_kernel; nullptr: its own index)
     uint32_t* mig_buf;             // device: suspended state of those pairs, mig_slot_dwords per boundary
     int mig_slot_dwords;           // (stride of a boundary's states in mig_buf)
+    int mig_identity;              // 1: lane group g owns interval g (debug option mig_identity: the schedule without the permutation, A/B runs)
     int mig_fallback;              // 1: the stride holds TWO states, the suspended one and a fallback (the older checkpoint of a pair that was suspended with a bound for its maximum)
     unsigned int mig_timeout_ticks;  // 100 MHz ticks a group waits for a pair that another group is RUNNING to be suspended before it takes the pair over
     unsigned int mig_fresh_timeout_ticks;   // ... and for a pair the other group has not even started (its workgroup is not resident)
@@ -68,6 +70,8 @@ struct AlignLaunch {
     int fast_anchor;               // 1: the window of key steps starts before the corner of the shorter sequence (default); 0: before the pair's last step (experiments)
     int static_ck;                 // on a static schedule the three-register-pair shapes: 1 = checkpoints and going back to them in place, 0 = none, a pair that must start over goes to the int32 kernel
     int launch_id;                 // a number per agatha_amd_align call (24 bits are stored with every checkpoint: a slot's content must be this call's)
+    int win_prior;                 // packed-int16 kernel: the adaptive part of the window of key steps a pair STARTS with: what a read with 15 % errors needs at this scoring (capi.cpp)
+    int win_cap_min, win_cap_div;  // packed-int16 kernel: the adaptive part of a pair's window of key steps is at most max(win_cap_min, steps / win_cap_div) steps
     int fast_margin;               // packed-int16 kernel: > 0 = value steps (align16_body.inc) except in a pair's last fast_margin steps; 0 = key steps only
     // ---- traceback pass (align_tb.hip): the compare kernel also records a 4-bit code per computed cell ----
     uint32_t* tb_codes;            // device: the code area; pair k's words start at tb_off[k]: 8 words (one per block row, a

@@ -185,7 +185,7 @@ def run_leg(ctx, config, pairs, scaling, steps, warmup, n_run_frac=0.0):
     """One timed leg: `steps` passes of the hot path over one batch of BASELINE.json config `config` (`pairs` per GPU when weak,
     in all when strong), bracketed by barrier + synchronize, MAX over ranks.  Returns a dict of what was measured (rank-0 view
     where it says so) plus the host batch of this rank (for the CPU baseline / the API timing of the caller)."""
-    import agatha_amd
+    agatha_amd = ctx.engine_mod
     from agatha_amd import workload, shard
     torch, dist, eng, stream = ctx.torch, ctx.dist, ctx.eng, ctx.stream
     rank, world, use_dist = ctx.rank, ctx.world, ctx.use_dist
@@ -229,15 +229,21 @@ def run_leg(ctx, config, pairs, scaling, steps, warmup, n_run_frac=0.0):
             total_batch_pairs = float(len(ql))
             qb, tb, qo, to, ql, tl = shard.take_pairs(qb, tb, qo, to, ql, tl, mine)
     t_gen = time.perf_counter() - t_gen
-    if len(ql) == 0:
-        raise SystemExit(f"rank {rank}: the partition left this rank without pairs ({pairs} pairs over {world} ranks)")
+    # (decided by all ranks together: one rank that left alone would leave the others waiting in the next collective)
+    empty = np.array([1.0 if len(ql) == 0 else 0.0])
+    if use_dist:
+        et_ = torch.from_numpy(empty).to(ctx.device)
+        dist.all_reduce(et_)
+        empty = et_.cpu().numpy()
+    if empty[0] > 0:
+        raise SystemExit(f"rank {rank}: the partition left {int(empty[0])} rank(s) without pairs ({pairs} pairs over {world} ranks): every rank stops")
     cells = int(shard.nominal_cells(ql, tl, W_BAND).sum())
     total_batch_cells = 0.0
     if strong:
         loads = np.zeros(world, np.float64)
         loads[rank] = cells
         if use_dist:
-            lt_ = torch.from_numpy(loads).cuda()
+            lt_ = torch.from_numpy(loads).to(ctx.device)
             dist.all_reduce(lt_)
             loads = lt_.cpu().numpy()
         imbalance = float(loads.max() / loads.mean())
@@ -247,14 +253,14 @@ def run_leg(ctx, config, pairs, scaling, steps, warmup, n_run_frac=0.0):
     b = eng.batch(qb, tb, qo, to, ql, tl)
     res_t = gathered = idx_t = None
     if use_dist:
-        res_t = torch.empty((3, b.n), dtype=torch.int32, device="cuda")
+        res_t = torch.empty((3, b.n), dtype=torch.int32, device=ctx.device)
         b.use_result_pointers([res_t[k].data_ptr() for k in range(3)])
         if strong:
-            idx_t = torch.from_numpy(np.asarray(mine, np.int64)).cuda()
+            idx_t = torch.from_numpy(np.asarray(mine, np.int64)).to(ctx.device)
         else:
-            gathered = torch.empty((world, 3, b.n), dtype=torch.int32, device="cuda")
+            gathered = torch.empty((world * 3, b.n), dtype=torch.int32, device=ctx.device)      # (concatenation along dim 0: RCCL and gloo)
     b.upload(stream)
-    eng.synchronize() if stream is None else torch.cuda.synchronize()
+    eng.synchronize() if stream is None else ctx.dev_sync()
 
     kev = [(eng.event(), eng.event()) for _ in range(steps)]
 
@@ -274,7 +280,7 @@ def run_leg(ctx, config, pairs, scaling, steps, warmup, n_run_frac=0.0):
 
     def sync():
         if use_dist:
-            torch.cuda.synchronize()
+            ctx.dev_sync()
             dist.barrier()
         else:
             eng.synchronize()
@@ -289,10 +295,10 @@ def run_leg(ctx, config, pairs, scaling, steps, warmup, n_run_frac=0.0):
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tc = torch.tensor([float(cells), float(b.n)], dtype=torch.float64, device="cuda")
+        tc = torch.tensor([float(cells), float(b.n)], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(tc, op=dist.ReduceOp.SUM)
         total_cells, total_pairs = float(tc[0].item()), float(tc[1].item())
     else:
@@ -305,11 +311,18 @@ def run_leg(ctx, config, pairs, scaling, steps, warmup, n_run_frac=0.0):
             # chunks -- and compares with what the N ranks gathered
             got = last.cpu().numpy()
             if chunked:
-                pick = np.unique(np.linspace(0, nch - 1, num=min(nch, 32)).astype(np.int64))
-                sb = workload.chunked_pairs(cfg["gen"], seed, lens, pick)
-                ref, ids_ = eng.align_host_batch(*sb[:6], scores), sb[6]
-                same = int(sum(int(all(int(ref[j][k]) == int(got[j][i]) for j in range(3))) for k, i in enumerate(ids_)))
-                strong_check = f"{same}/{len(ids_)} pairs (32 chunks spread over the batch) identical to the same pairs aligned on one GPU"
+                # ALL of the batch, a few thousand pairs at a time (the chunks are made again from their own random streams: rank 0
+                # never holds the whole batch), each piece aligned on this one GPU
+                same = looked = 0
+                piece = max(1, ctx.check_pairs_per_piece // workload.CHUNK)
+                for c0 in range(0, nch, piece):
+                    sb = workload.chunked_pairs(cfg["gen"], seed, lens, np.arange(c0, min(nch, c0 + piece)))
+                    ref, ids_ = eng.align_host_batch(*sb[:6], scores), sb[6]
+                    ok = np.ones(len(ids_), bool)
+                    for j in range(3):
+                        ok &= np.asarray(ref[j]) == got[j][ids_]
+                    same += int(ok.sum()); looked += len(ids_)
+                strong_check = f"{same}/{looked} pairs (the whole batch, {piece * workload.CHUNK} pairs at a time) identical to the same pairs aligned on one GPU"
             else:
                 ref = eng.align_host_batch(*full, scores)
                 same = int(sum(int(all(int(ref[j][i]) == int(got[j][i]) for j in range(3))) for i in range(len(full[4]))))
@@ -334,6 +347,20 @@ def run_leg(ctx, config, pairs, scaling, steps, warmup, n_run_frac=0.0):
                 host_batch=(qb, tb, qo, to, ql, tl), W=W_BAND, Z=Z)
 
 
+def recorded_1gpu(SL):
+    """The strong batch's time on ONE MI355X, recorded once with `python bench.py --config C2 --scaling strong --pairs 100000 --no-cpu-baseline
+    --no-gasal-api` (profiles/strong_1gpu.json: tools/record_strong_1gpu.py), so that an N-GPU run has something to divide by."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "strong_1gpu.json")))
+        if rec.get("config") == SL["config"] and int(rec.get("pairs", 0)) == int(SL["pairs"]) and rec.get("scoring") == "m{m}x{x}q{q}r{r}".format(**SL["cfg"]["scoring"]):
+            ms = SL["elapsed"] / max(SL["steps"], 1) * 1e3
+            return {"recorded_1gpu_ms_per_step": rec["ms_per_step"], "recorded_1gpu_source": rec.get("source"),
+                    "speedup_vs_recorded_1gpu": rec["ms_per_step"] / ms if ms > 0 else None}
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"recorded_1gpu_ms_per_step": None, "speedup_vs_recorded_1gpu": None}
+
+
 def workload_text(L):
     cfg = L["cfg"]
     return (f"{L['config']}: {L['pairs']} {cfg['text']}, " + (f"{L['n_run_frac']:.0%} of the DP-row sequences with a run of N, " if L["n_run_frac"] > 0 else "") +
@@ -354,16 +381,25 @@ def main():
     ap.add_argument("--config", default="C1", choices=sorted(CONFIGS), help="workload shape of BASELINE.json (default C1 = configs[1], the headline)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank aligns its own batch; strong: ONE batch, LPT-sharded over the ranks, results gathered")
+    ap.add_argument("--scoring", default="", help="m<a>x<b>q<o>r<e>, e.g. m1x4q6r2 = the reference's own bench command (AGAThA.sh:44); default: the config's scoring "
+                                                   "(m2x4q4r2, the library / CLI defaults, args_parser.cpp:12-15)")
     ap.add_argument("--n-run-frac", type=float, default=0.0, help="fraction of the DP-row sequences (file 1: reference pieces) that carry a run of N (50-1000 bases)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gasal-api", action="store_true", help="skip the timing of the CLI / GASAL API by the reference's raw.log protocol")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the sustained stream/batch-manager leg (gasal_aln_async over 16 batches)")
     ap.add_argument("--strong-pairs", type=int, default=100000, help="N > 1: pairs of the ONE sharded batch of the `strong` object (BASELINE configs[2]); 0 = no strong leg")
+    ap.add_argument("--strong-steps", type=int, default=10, help="N > 1: timed steps of the strong leg (at least --steps)")
     ap.add_argument("--force-strong-leg", action="store_true", help="run the strong leg under a launcher with ONE rank as well (checks the N > 1 code path on a 1-GPU box)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     if a.pairs <= 0:
         a.pairs = cfg["pairs"]
+    if a.scoring:
+        import re
+        mm = re.fullmatch(r"m(\d+)x(\d+)q(\d+)r(\d+)", a.scoring)
+        if not mm:
+            raise SystemExit("--scoring: m<match>x<mismatch>q<gap open>r<gap extend>, e.g. m1x4q6r2")
+        CONFIGS[a.config] = cfg = dict(cfg, scoring=dict(zip("mxqr", map(int, mm.groups()))))
 
     # RCCL / HIP print banners to fd 1 on some boxes (NCCL_DEBUG=VERSION): keep stdout clean for the ONE JSON line
     sys.stdout.flush()
@@ -377,28 +413,44 @@ def main():
     ctx.use_dist = use_dist = "WORLD_SIZE" in os.environ
     ctx.torch = ctx.dist = torch = dist = None
     n_ranks_rccl = None
+    # (tests only: AGATHA_BENCH_BACKEND=gloo + AGATHA_BENCH_ENGINE=<module> run the whole of this file -- legs, collectives, the ONE
+    #  JSON line -- over CPU ranks with a stand-in for the engine; tests/test_bench_strong_leg.py)
+    backend = os.environ.get("AGATHA_BENCH_BACKEND", "nccl")
+    ctx.device = "cuda" if backend == "nccl" else "cpu"
+    ctx.dev_sync = lambda: None
+    ctx.check_pairs_per_piece = int(os.environ.get("AGATHA_BENCH_CHECK_PIECE", "4096"))
     if use_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            ctx.dev_sync = torch.cuda.synchronize
+        else:
+            dist.init_process_group(backend)
         ctx.torch, ctx.dist = torch, dist
         n_ranks_rccl = dist.get_world_size()
     if world != a.gpus and rank == 0:
         print(f"[bench] note: WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
 
-    import agatha_amd
+    if os.environ.get("AGATHA_BENCH_ENGINE"):
+        import importlib
+        agatha_amd = importlib.import_module(os.environ["AGATHA_BENCH_ENGINE"])
+    else:
+        import agatha_amd
+    ctx.engine_mod = agatha_amd
 
     ctx.eng = eng = agatha_amd.Engine(local_rank)
     ctx.stream = None
-    if use_dist:
+    if use_dist and backend == "nccl":
         ctx.stream = torch.cuda.current_stream().cuda_stream   # run on torch's stream so the gather is ordered behind align
 
     L = run_leg(ctx, a.config, a.pairs, a.scaling, a.steps, a.warmup, a.n_run_frac)
     strong_leg = None
     if use_dist and (world > 1 or a.force_strong_leg) and a.scaling == "weak" and a.strong_pairs > 0:
         # the sharded batch BASELINE.json names for 8 GPUs (configs[2]: 100 000 HiFi pairs), strong scaling, in the same run
-        strong_leg = run_leg(ctx, "C2", a.strong_pairs, "strong", min(a.steps, 3) if a.steps else 0, 1)
+        # (at least 10 timed steps behind 2 warm-up steps: a step of an eighth of the batch is ~45 ms, three of them were noise)
+        strong_leg = run_leg(ctx, "C2", a.strong_pairs, "strong", max(a.steps, a.strong_steps) if a.steps else 0, max(a.warmup, 2))
 
     kernel_ms, cells, kind, kname = L["kernel_ms"], L["cells_rank0"], L["kind"], L["kname"]
     abytes, strong = L["abytes"], a.scaling == "strong"
@@ -412,7 +464,8 @@ def main():
         pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
         same_kernel = pm.get("kernel", "").replace(" ", "").startswith(kname.rstrip(">").replace(" ", "") + ",") or \
             pm.get("kernel", "").replace(" ", "") == kname.replace(" ", "")
-        if pm.get("pairs") == a.pairs and pm.get("config", "C1") == a.config and same_kernel and not strong and \
+        sc_name = "m{m}x{x}q{q}r{r}".format(**cfg["scoring"])
+        if pm.get("pairs") == a.pairs and pm.get("config", "C1") == a.config and pm.get("scoring", "m2x4q4r2") == sc_name and same_kernel and not strong and \
                 bool(pm.get("preemptive_schedule", False)) == bool(L["sched"][0]):
             traffic = float(pm["hbm_bytes_per_launch"])
             issued = pm.get("valu_insts_per_launch")
@@ -480,6 +533,7 @@ def main():
                              "workload": workload_text(SL), "pairs_rank0": SL["n_local"], "kernel": SL["kname"], "kernel_ms_rank0": SL["kernel_ms"],
                              "shard_imbalance_max_over_mean": SL["imbalance"], "strong_scaling_check": SL["strong_check"],
                              "host_seconds_to_make_the_rank0_shard": round(SL["t_gen"], 2), "n_ranks_seen_by_rccl": n_ranks_rccl,
+                             **recorded_1gpu(SL),
                              "step": "pack + sort + align + RCCL all-gather of results and pair ids (input order restored on every rank)"}
         qb, tb, qo, to, ql, tl = L["host_batch"]
         if world == 1 and not a.no_gasal_api and a.config in ("C0", "C1"):
@@ -494,8 +548,19 @@ def main():
                 runs = gasal_api_timing.time_config(qs_host, ts_host, cfg["scoring"], W_BAND, Z, combos=((a.pairs, 1), (8192, 1)))
                 for r in runs:
                     r.pop("per_batch"); r.pop("score_log")
+                # ... and the reference's ONE bench command verbatim (AGAThA.sh:44: `manual -p -m 1 -x 4 -q 6 -r 2 -s 3 -z 400 -w 751`, library
+                # defaults -a 8192 -n 1), whatever scoring the rest of this run uses: its raw.log sum is what AGAThA.sh averages into time.json
+                ref_scoring = dict(m=1, x=4, q=6, r=2)
+                ref_cmd = gasal_api_timing.time_config(qs_host, ts_host, ref_scoring, 751, 400, combos=((8192, 1),))[0]
+                ref_cmd.pop("score_log")
+                pb = ref_cmd.pop("per_batch")
+                from agatha_amd import shard as _shard
+                ref_cells = float(_shard.nominal_cells(np.asarray(ql, np.int64), np.asarray(tl, np.int64), 751).sum())
+                ref_cmd.update(gcups_by_raw_log=ref_cells / max(ref_cmd["kernel_ms_sum"], 1e-9) / 1e6,
+                               pairs_started_over=sum(b["pairs_started_over"] for b in pb), went_back_to_checkpoint=sum(b["went_back_to_checkpoint"] for b in pb),
+                               key_wave_steps=sum(b["key_wave_steps"] for b in pb), value_wave_steps=sum(b["value_wave_steps"] for b in pb))
                 out["gasal_api"] = {"protocol": "agatha_amd/manual -p (reference AGAThA.sh:44,52, gasal_align.cu:219-236): kernel ms per batch as written to raw.log by libgasal_amd.so; two streams per host thread",
-                                    "runs": runs,
+                                    "runs": runs, "reference_bench_command": ref_cmd,
                                     "kernel_ms_per_batch_of_all_pairs": runs[0]["kernel_ms_sum"],
                                     "vs_kernel_ms": runs[0]["kernel_ms_sum"] / kernel_ms if kernel_ms else None}
                 if not a.no_pipeline and a.config == "C1":

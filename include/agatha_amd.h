@@ -107,7 +107,10 @@ int agatha_amd_seq_ops(void* stream, const uint8_t* d_unpacked, uint32_t* d_pack
 /* Sort + align one batch.  Replaces agatha_kernel_launcher (gasal_align.cu:10-23): the agatha_sort kernel,
  * its D2H / host std::sort / H2D round trip, and agatha_kernel itself.
  * max_query_len / max_target_len: upper bounds of the lengths in this batch (0 = unknown); they only let
- * short batches run on a narrower lane group and never change results. */
+ * short batches run on a narrower lane group and never change results.
+ * Threads: one caller per (device, stream) at a time -- the call forks a helper stream that belongs to that pair (kept per device:
+ * the null stream is the same handle on every GPU) and joins it again before it returns; different streams, or the same stream
+ * handle on different devices, may be driven from different host threads concurrently. */
 int agatha_amd_align(void* stream,
                      const uint32_t* d_packed_query, const uint32_t* d_packed_target,
                      const uint32_t* d_query_lens, const uint32_t* d_target_lens,

@@ -18,6 +18,7 @@
 #include <string.h>
 #include <limits.h>
 #include <stdio.h>
+#include <math.h>
 
 #define NEG_INF2 (-16384)
 #define N_VALUE 14
@@ -317,6 +318,8 @@ static void init_col16(lane_t *ln, int s, int r, int R, int prl, int w, int gapo
  * The model keeps exact keys all along; what it checks is the DECISION logic: whenever it returns 0 with a margin, the result
  * must be the oracle's. */
 __thread int agatha_lanes16_margin = 0;
+int agatha_lanes16_win_cap_min = 128, agatha_lanes16_win_cap_div = 16;     /* the kernel's debug options of the same names */
+int agatha_lanes16_old_window = 0;        /* tools: round 4's rule for the window of key steps (3/2 (slack + 7 ge) i / best) */
 
 int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_params_t *pr,
                          int G, int S, int32_t *out3, int32_t *stats)
@@ -348,7 +351,15 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
         for (int x = 0; x < 7; x++) { L[k].CAR[0][x] = INT_MIN; L[k].CAR[1][x] = INT_MIN; }
     }
     const int slack = 7 * imax(b, 1);
-    int ewin = 2 * (pql < prl ? pql : prl) - 1 - margin - ((pql + prl) >> 7);      /* first step of the window of key steps */
+    /* first step of the window of key steps: what a read with 15 % errors needs at this scoring (capi.cpp: win_prior), capped */
+    const int win_anchor = 2 * (pql < prl ? pql : prl) - 1 - margin - ((pql + prl) >> 7);
+    int ewin = win_anchor;
+    if (!agatha_lanes16_old_window) {
+        const double pen_ = a + b > 0.5 * a + gapoe ? a + b : 0.5 * a + gapoe, mu_ = 4.0 * (a - 0.15 * pen_), V_ = 4.0 * 0.15 * pen_ * pen_;
+        double n_ = 4096.0;
+        if (mu_ > 0.0) { const double r_ = (sqrt(12.0 * V_) + sqrt(12.0 * V_ + 4.0 * mu_ * (slack + 7 * ge))) / (2.0 * mu_); n_ = r_ * r_ < 4096.0 ? r_ * r_ : 4096.0; }
+        ewin = win_anchor - imin((int)ceil(n_), imax(agatha_lanes16_win_cap_min, (pql + prl) / imax(agatha_lanes16_win_cap_div, 1)));
+    }
     int64_t lo_prev_abs = INT_MIN;      /* value steps: lower bound (absolute score) of the maxima of this step's anti-diagonals 0..6 */
     int best = 0, best_t = 0, best_q = 0, stopped = 0, bail = 0;
     int i = 0, y = 0, final = 0, cb_prev = 0;
@@ -359,6 +370,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
 
     for (;;) {
         const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
+        int n_in_flight = 0;        /* a block of this step works on a query word that holds an N (or the padding behind the query's end) */
         for (int k = 0; k < G; k++)
             for (int x = 0; x < 7; x++) L[k].A[x] = ssub_sat(L[k].A[x], cb - cb_prev);
         for (int k = 0; k < G; k++) {
@@ -369,6 +381,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 const int active = !final && r < prl && q >= cs && q <= ce && r >= ss && r <= se;
                 ln->bhi[s] = INT_MIN; ln->blo[s] = INT_MIN;
                 if (!active) { ln->xr[s + 1] = -2; continue; }
+                if (pq[q] & 0x88888888u) n_in_flight = 1;
                 if (y == 0)
                     for (int m = 0; m < 8; m++) if (8 * r + m >= R) { ln->h[s][m] = L16_NEG; ln->f[s][m] = L16_NEG; }
                 int32_t xh[8], xe[8], xe_in[8];
@@ -465,9 +478,22 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
          *  the corner the shorter sequence ends in, to the pair's end; and the pair's first step) */
         /* (the bound of a value step lies up to slack + 7 ge above the running maximum, and the key steps must see the score rise by
          *  more than that: every 64 steps the window is widened by the steps that takes at the pair's rate so far, 3/2 of them) */
-        if (margin > 0 && i > 0 && (i & 63) == 0 && best > 0)
-            ewin = imin(ewin, 2 * (pql < prl ? pql : prl) - 1 - margin - ((pql + prl) >> 7) - (int)(((int64_t)3 * (slack + 7 * ge) * i) / (2 * (int64_t)best)));
-        const int fast = margin > 0 && i >= 1 && i < ewin;
+        /* (round 5: widen_window of align16_body.inc -- the steps a random walk with the pair's rate of rise and the variance its error
+         *  rate implies needs to rise by more than slack + 7 ge except with the probability of a 3.5-sigma event) */
+        if (margin > 0 && i > 0 && (i & 63) == 0 && best > 0 && (agatha_lanes16_old_window || i < ewin)) {
+            const int64_t err4 = imax(4 * i * a - best, 0), pen2 = imax(2 * (a + b), a + 2 * gapoe), X_ = slack + 7 * ge;
+            int64_t more = ((6 * err4 * pen2 + 2 * (int64_t)best * X_) * i) / ((int64_t)best * best);
+            if (agatha_lanes16_old_window) {
+                more = ((int64_t)3 * X_ * i) / (2 * (int64_t)best);
+                ewin = imin(ewin, win_anchor - (int)(more < 4096 ? more : 4096));
+            } else {
+                /* (what the pair shows of itself may move the window either way while it is still on value steps) */
+                const int64_t cap = imax(agatha_lanes16_win_cap_min, (pql + prl) / imax(agatha_lanes16_win_cap_div, 1));
+                ewin = imax(win_anchor - (int)(more < cap ? more : cap), i);
+            }
+        }
+        /* (a wave runs key steps while a pair whose query holds an N has an N row in flight: align16_body.inc, want_keys) */
+        const int fast = margin > 0 && i >= 1 && i < ewin && !n_in_flight;
         int calm = 0, stale = 0;
         int32_t HI = INT_MIN;
         if (margin > 0) {

@@ -355,6 +355,7 @@ int agatha_model_traceback(const char *qs, int Q, const char *rs, int R, const o
  * (max(best, largest H) - smallest anti-diagonal maximum > z), st[3] = the first such step (-1: none),
  * st[4] = 1 if the pair stopped on z-drop, st[5] = steps that raised the maximum, st[6] = total steps of the pair. */
 __thread int32_t *agatha_steps_stats = 0;
+__thread int32_t *agatha_steps_trace = 0;      /* tools/cliff_sweep.py: the running maximum behind every step */
 
 void agatha_model_steps(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr,
                         int wide, oracle_result_t *out)
@@ -411,6 +412,7 @@ void agatha_model_steps(const char *qs, int Q, const char *rs, int R, const orac
                 st[0] = i + 1;
                 if (8 * i + 7 < lim && z >= 0 && imax(zs.best, hmax) - hmin > z) { st[2]++; if (st[3] < 0) st[3] = i; }
                 if (hmax > zs.best) { st[1] = i; st[5]++; }
+                if (agatha_steps_trace) agatha_steps_trace[i] = imax(zs.best, hmax);
             }
             /* anti-diagonals 8i..8i+7 are complete after step i */
             for (int d = 8 * i; d < 8 * i + 8 && d < lim; d++) {
@@ -434,6 +436,16 @@ void agatha_model_steps(const char *qs, int Q, const char *rs, int R, const orac
     out->score = zs.best; out->query_end = zs.best_q; out->target_end = zs.best_t;
     if (agatha_steps_stats) { agatha_steps_stats[4] = zs.stopped && !done && i0 < total; agatha_steps_stats[6] = total; }
     free(H); free(started); free(cx.rowH); free(cx.dmax); free(qc); free(rc);
+}
+
+/* one pair: stats7 as below, trace[i] = the running maximum behind step i (trace holds ceil(Q/8) + ceil(R/8) entries) */
+void agatha_steps_trace_pair(const char *qs, int Q, const char *rs, int R, const oracle_params_t *pr, int32_t *stats7, int32_t *trace)
+{
+    oracle_result_t res;
+    stats7[0] = 0; stats7[1] = -1; stats7[2] = 0; stats7[3] = -1; stats7[4] = 0; stats7[5] = 0; stats7[6] = 0;
+    agatha_steps_stats = stats7; agatha_steps_trace = trace;
+    agatha_model_steps(qs, Q, rs, R, pr, 1, &res);
+    agatha_steps_stats = 0; agatha_steps_trace = 0;
 }
 
 void agatha_steps_stats_batch(const uint8_t *qbatch, const uint8_t *tbatch, const uint32_t *qoff, const uint32_t *toff,

@@ -1,0 +1,125 @@
+"""CPU only: a standing sweep for performance cliffs of the packed-int16 kernel's speculative value steps.
+
+The kernel's results are exact whatever happens; its SPEED depends on how many pairs a value step could not decide and had to be
+started over (on key steps, from a checkpoint or from their first step), and on how many pairs leave for the int32 kernel.  The
+decision logic is emulated lane for lane by oracle/agatha_lanes_model.c (agatha_model_lanes16 with a margin); this tool runs it over
+
+    {scorings} x {error rates} x {target cut to a fraction of its length} x {N-run fraction} x {C0, C1, C2 shapes}
+
+and prints, per cell, the share of pairs started over (kind 2), handed to the int32 kernel (kind 1) and -- from the plain oracle
+-- z-dropped, so that a cell with many pairs started over on reads that do NOT break stands out.  Every result is also checked
+against the oracle (a mismatch is a bug, not a cliff).  Minutes on 8 cores; no GPU.
+
+    python tools/cliff_sweep.py [--pairs-scale 1.0] [--quick] [--out profiles/r05_v1/cliff_sweep.txt] [--margin 12]
+"""
+import argparse
+import itertools
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O                      # noqa: E402
+from agatha_amd import workload as wl               # noqa: E402
+
+# (name, m, x, q, r): AGAThA / minimap2 map-ont defaults; the reference's bench command (AGAThA.sh:44) = minimap2 map-hifi's first
+# gap cost; minimap2 asm10 and asm5; minimap2 sr
+SCORINGS = [("m2x4q4r2", 2, 4, 4, 2), ("m1x4q6r2", 1, 4, 6, 2), ("m1x9q16r2", 1, 9, 16, 2), ("m1x19q39r3", 1, 19, 39, 3), ("m2x8q12r2", 2, 8, 12, 2)]
+ERRORS = [0.01, 0.05, 0.10, 0.15]
+CUTS = [1.0, 0.9, 0.75]
+NFRACS = [0.0, 0.02]
+# shape: (name, length law, band, pairs per cell)
+SHAPES = [("C0", lambda rng: int(np.clip(np.rint(rng.normal(3000, 1000)), 200, 8000)), 751, 240),
+          ("C1", lambda rng: int(np.clip(np.rint(rng.normal(10000, 1000)), 8000, 12000)), 751, 96),
+          ("C2", lambda rng: int(rng.integers(15000, 20001)), 500, 48)]
+
+
+def shape_gs(band):
+    """lanes / slots of the int16 throughput shape for this band (align16_kernel.hip: kCfgs16)"""
+    win = (band + 7) // 8 + 1
+    for g, s in ((16, 2), (16, 4), (16, 6), (32, 4), (32, 6), (64, 4), (64, 6)):
+        if g * s >= win:
+            return g, s
+    raise ValueError(band)
+
+
+def make_cell(seed, n, length_fn, err, cut, nfrac):
+    sub, ins, dele = 0.3 * err, 0.3 * err, 0.4 * err
+    qs, ts = wl.make_pairs(seed, n, length_fn, sub, ins, dele)
+    if cut < 1.0:
+        ts = [t[:max(1, int(len(t) * cut))] for t in ts]
+    if nfrac > 0:
+        qs = wl.add_n_runs(qs, nfrac, seed=seed + 1)
+    return qs, ts
+
+
+def run_cell(qs, ts, scoring, band, margin, threads):
+    _, m, x, q, r = scoring
+    p = O.make_params(m=m, x=x, q=q, r=r, w=band)
+    qb, qo, ql = wl.make_batch(qs)
+    tb, to, tl = wl.make_batch(ts)
+    G, S = shape_gs(band)
+    got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, G, S, threads=threads, value_step_margin=margin)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=threads)
+    bad = int(sum(1 for k in range(len(ql)) if any(int(got[j][k]) != int(exp[j][k]) for j in range(3))))
+    kind = got[3]
+    # z-dropped (by the plain oracle's count of the anti-diagonals it walked): a pair that ends before its last anti-diagonal
+    lib = O.lib()
+    import ctypes as C
+    lib.agatha_steps_stats_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.POINTER(O.Params), C.c_int, C.c_void_p]
+    st = np.zeros((len(ql), 7), np.int32)
+    lib.agatha_steps_stats_batch(qb.ctypes.data, tb.ctypes.data, qo.ctypes.data, to.ctypes.data, ql.ctypes.data, tl.ctypes.data,
+                                 len(ql), C.byref(p), threads, st.ctypes.data)
+    zd = st[:, 4] != 0
+    over = kind == 2
+    return dict(n=len(ql), over=int(over.sum()), over_clean=int((over & ~zd).sum()), back=int((kind == 1).sum()), zdrop=int(zd.sum()),
+                mismatch=bad, ineligible=int((kind == 1).sum()) == len(ql))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs-scale", type=float, default=1.0)
+    ap.add_argument("--quick", action="store_true", help="two scorings, two error rates, no cut, no N runs (a smoke run)")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--margin", type=int, default=12, help="fast_margin of the kernel (debug option of the same name)")
+    ap.add_argument("--threads", type=int, default=max(1, len(os.sched_getaffinity(0))))
+    ap.add_argument("--shapes", default="C0,C1,C2")
+    a = ap.parse_args()
+    scorings, errors, cuts, nfracs = SCORINGS, ERRORS, CUTS, NFRACS
+    if a.quick:
+        scorings, errors, cuts, nfracs = SCORINGS[:2], [0.05, 0.10], [1.0], [0.0]
+    shapes = [s for s in SHAPES if s[0] in a.shapes.split(",")]
+    lines = []
+
+    def emit(s):
+        print(s, flush=True)
+        lines.append(s)
+
+    emit(f"# tools/cliff_sweep.py margin={a.margin} pairs-scale={a.pairs_scale}: oracle/agatha_lanes_model.c (agatha_model_lanes16), every result checked against the oracle")
+    emit("# started over = a value step could not decide / the pair ended without the cell of its maximum (kernel: back to a checkpoint or to its first step, on key steps);")
+    emit("# 'clean' = of pairs the oracle does NOT z-drop; handed back = left for the int32 kernel; columns in % of the cell's pairs")
+    emit(f"{'shape':5s} {'scoring':11s} {'err':>4s} {'cut':>5s} {'Nrun':>5s} {'pairs':>5s} {'zdrop%':>7s} {'over%':>7s} {'over-clean%':>11s} {'back%':>6s} {'mismatch':>8s}")
+    t0 = time.time()
+    worst = []
+    for (sname, lfn, band, npairs), sc, err, cut, nf in itertools.product(shapes, scorings, errors, cuts, nfracs):
+        n = max(8, int(npairs * a.pairs_scale))
+        seed = 0xC11FF + hash((sname, sc[0], err, cut, nf)) % 100000
+        qs, ts = make_cell(seed, n, lfn, err, cut, nf)
+        r = run_cell(qs, ts, sc, band, a.margin, a.threads)
+        pc = lambda v: 100.0 * v / r["n"]
+        emit(f"{sname:5s} {sc[0]:11s} {err:4.2f} {cut:5.2f} {nf:5.2f} {r['n']:5d} {pc(r['zdrop']):7.1f} {pc(r['over']):7.2f} {pc(r['over_clean']):11.2f} {pc(r['back']):6.1f} {r['mismatch']:8d}")
+        worst.append((pc(r["over_clean"]), sname, sc[0], err, cut, nf))
+        assert r["mismatch"] == 0, "the int16 model disagrees with the oracle"
+    worst.sort(reverse=True)
+    emit(f"# {len(worst)} cells in {time.time() - t0:.0f} s; the ten worst by pairs started over although they do not z-drop:")
+    for w in worst[:10]:
+        emit(f"#   {w[0]:6.2f} %  {w[1]} {w[2]} err {w[3]} cut {w[4]} N-run {w[5]}")
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        open(a.out, "w").write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,9 @@ qs, ts = getattr(workload, cfgname)(n=n)
 qb, qo, ql = workload.make_batch(qs); tb, to, tl = workload.make_batch(ts)
 b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); eng.synchronize()
 W = int(os.environ.get("BAND", {"cfg_c2": 500, "cfg_c3": 1500}.get(cfgname, 751)))
-sc = agatha_amd.Scores.make(w=W)
+# SCORING=m,x,q,r (default the library's m2 x4 q4 r2; the reference's bench command, AGAThA.sh:44, is 1,4,6,2)
+m_, x_, q_, r_ = (int(v) for v in os.environ.get("SCORING", "2,4,4,2").split(","))
+sc = agatha_amd.Scores.make(m=m_, x=x_, q=q_, r=r_, w=W)
 defaults = {}
 for spec in sys.argv[3:] or [""]:
     opts = dict(a.split("=") for a in spec.split(",") if a)

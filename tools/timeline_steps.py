@@ -12,7 +12,8 @@ eng = agatha_amd.Engine(0)
 qs, ts = getattr(workload, cfgname)(n=n)
 qb, qo, ql = workload.make_batch(qs); tb, to, tl = workload.make_batch(ts)
 b = eng.batch(qb, tb, qo, to, ql, tl); b.upload(); b.pack(); eng.synchronize()
-sc = agatha_amd.Scores.make(w=int(opts.pop("w", 751)))
+m_, x_, q_, r_ = (int(v) for v in os.environ.get("SCORING", "2,4,4,2").split(","))
+sc = agatha_amd.Scores.make(m=m_, x=x_, q=q_, r=r_, w=int(opts.pop("w", 751)))
 agatha_amd.set_debug_option("timeline", 1)
 for k, v in opts.items():
     agatha_amd.set_debug_option(k, int(v))
@@ -42,5 +43,9 @@ for x in range(8):
     if m.any(): print("  xcc %d: end median %.0f max %.0f us/step %.3f" % (x, np.median(en[m]), en[m].max(), np.median((life / steps)[m])))
 if os.environ.get("TIMELINE_DUMP"):
     np.save(os.environ["TIMELINE_DUMP"], t)
+# waves by their number of key steps: how long they live
+for lo_, hi_ in ((0, 100), (100, 200), (200, 300), (300, 400), (400, 600), (600, 900), (900, 100000)):
+    m = (keys >= lo_) & (keys < hi_)
+    if m.any(): print("  waves with %4d..%-5d key steps: %5d, life median %.0f us, end median %.0f max %.0f, us per value step (life - 1.35 x key) %.3f" % (lo_, hi_, m.sum(), np.median(life[m]), np.median(en[m]), en[m].max(), np.median((life[m]) / (fast[m] + 1.35 * keys[m]))))
 print("corr(end, key steps) %.2f corr(end, steps) %.2f" % (np.corrcoef(en, keys)[0, 1], np.corrcoef(en, steps)[0, 1]))
 b.free()
