@@ -38,8 +38,8 @@ int align16_mig_fields(int P) { return mig_fields(P); }
 bool agatha16_scores_ok(const AlignParams& p)
 {
     if (p.band_width < 16) return false;
-    if (p.match < 0 || p.match > 16 || p.mismatch < 0 || p.mismatch > 32) return false;
-    if (p.gap_open < 0 || p.gap_open > 64 || p.gap_extend < 0 || p.gap_extend > 16) return false;
+    if (p.match < 0 || p.match > kAlign16MaxMatch || p.mismatch < 0 || p.mismatch > kAlign16MaxMismatch) return false;
+    if (p.gap_open < 0 || p.gap_open > kAlign16MaxGapOpen || p.gap_extend < 0 || p.gap_extend > kAlign16MaxGapExtend) return false;
     int per = 2 * p.gap_extend; if (p.mismatch > per) per = p.mismatch; if (per < 1) per = 1;
     const int spread = p.gap_open + p.gap_extend + per * (p.band_width + 16) + 64;
     return spread <= kAlign16MaxSpread;

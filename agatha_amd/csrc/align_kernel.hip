@@ -546,50 +546,61 @@ schedule_kernel(AlignLaunch L, int GS, int G)
     __syncthreads();
     uint32_t acc = part[t];
     for (int j = j0; j < j1; j++) { L.cum[j] = acc; acc += steps_of(j); }
-    // ---- which physical lane group owns which interval (round 5) ----
-    // A wave runs key steps while ANY of its lane groups' pairs is in the window at its end (align16_body.inc, want_keys), so a wave
-    // whose four intervals end their pairs at four different times runs four windows.  Every interval ends with the rest of the
-    // pair that crosses out of it (at step T, the same for all); what differs is where a WHOLE pair ends inside an interval --
-    // about one interval in five has one (n pairs on m > n / 2 groups).  The intervals are sorted by the step at which their first
-    // whole pair ends (T: none does), and consecutive intervals of that order go to the lane groups of one wave, consecutive waves
-    // to one CU (workgroups b and b + half share a CU on a full persistent grid): the windows of a wave, and of the waves that share
-    // an instruction cache, then coincide.  Counting sort over 2048 bins of the step, one workgroup.
+    // ---- the pool of suspended pairs' rests, and which physical lane group owns which interval (round 5) ----
+    // Boundary b T (b = 1 .. m - 1) cuts the pair that lies across it: lane group (interval) b runs its first steps and suspends it; its
+    // REST, the L_b = b T - cum[pair] steps before the boundary, is resumed by whoever draws it from the pool: the boundaries sorted by
+    // L_b, longest first (mig_late: [0] the pool's head, [1] how many, [2..] the boundaries).  A lane group is done with the fixed part of
+    // its interval after T - L_(g+1) steps, so with every group on time each one finds its own interval's rest on top of the pool --
+    // McNaughton's schedule --, and a group that is ahead or behind finds a longer or a shorter one.
+    // A wave runs key steps while ANY of its lane groups' pairs is in the window at its end (align16_body.inc, want_keys), so the four
+    // lane groups of a wave should end their pairs together: the intervals are dealt to the physical lane groups in the order of their
+    // rest L_(g+1) -- the four groups of a wave are then done with their fixed parts within a step or two of each other, draw
+    // neighbouring rests of the pool, and end those together --, consecutive waves of that order on one CU (workgroups b and b + half
+    // share a CU on a full persistent grid).  Counting sorts over 2048 bins of the step, one workgroup.
     if (L.mig_perm == nullptr) return;
+    const bool have_pool = L.mig_late != nullptr;        // (debug option no_pool: the permutation alone)
     __shared__ uint32_t bins[2048];
     __threadfence_block();
     __syncthreads();
     const int T_ = L.sched[1];
-    const bool use_ = L.sched[0] != 0 && T_ > 0 && !L.mig_identity;
-    for (int b = t; b < 2048; b += 1024) bins[b] = 0u;
-    __syncthreads();
-    auto end_key = [&](int g) -> uint32_t {
-        // first pair that reaches beyond the start of the interval (the kernel's own search), then the first one that lies whole inside
-        const uint32_t lo = (uint32_t)g * (uint32_t)T_, hi = lo + (uint32_t)T_;
-        int a = 0, b = n;
-        while (a < b) { const int mid = (a + b) >> 1; if (L.cum[mid + 1] > lo) b = mid; else a = mid + 1; }
-        for (int j = a; j < n && L.cum[j] < hi; j++) {
-            const uint32_t c = L.cum[j], c1 = L.cum[j + 1];
-            if (c1 == c || c < lo) continue;
-            if (c1 <= hi) return c1 - lo;           // a whole pair: it ends c1 - lo steps into the interval
-            break;
-        }
-        return (uint32_t)T_;
+    const bool use_ = L.sched[0] != 0 && T_ > 0;
+    if (t == 0 && have_pool) { L.mig_late[0] = 0; L.mig_late[1] = 0; }
+    if (!use_) { for (int g = t; g < m; g += 1024) L.mig_perm[g] = g; return; }
+    // rest of the pair across boundary b (0: the boundary falls between two pairs, or b is no boundary)
+    auto rest_of = [&](int b) -> uint32_t {
+        if (b <= 0 || b >= m) return 0u;
+        const uint32_t at = (uint32_t)b * (uint32_t)T_;
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.cum[mid + 1] > at) hi = mid; else lo = mid + 1; }
+        if (lo >= n) return 0u;
+        const uint32_t c = L.cum[lo];
+        return c < at ? at - c : 0u;
     };
-    auto bin_of = [&](uint32_t key) -> uint32_t { return (uint32_t)(((unsigned long long)key * 2047ull) / (unsigned long long)T_); };
-    if (use_) {
-        for (int g = t; g < m; g += 1024) atomicAdd(&bins[bin_of(end_key(g))], 1u);
-    }
-    __syncthreads();
-    if (t == 0 && use_) { uint32_t a = 0; for (int b = 0; b < 2048; b++) { const uint32_t v = bins[b]; bins[b] = a; a += v; } }
-    __syncthreads();
-    const int gpb = m / (2 * L.num_cus) > 0 ? m / (2 * L.num_cus) : 1, half = L.num_cus;     // lane groups per workgroup; workgroups per half of the grid
-    for (int g = t; g < m; g += 1024) {
-        if (!use_ || m != 2 * L.num_cus * gpb) { L.mig_perm[g] = g; continue; }
-        const uint32_t u = atomicAdd(&bins[bin_of(end_key(g))], 1u);       // rank of interval g in the sorted order
-        // rank u -> physical lane group: CU u / (2 gpb), its first workgroup for the first gpb ranks, its second for the rest
-        const int cu = (int)(u / (uint32_t)(2 * gpb)), within = (int)(u % (uint32_t)(2 * gpb));
-        const int blk = within < gpb ? cu : cu + half;
-        L.mig_perm[blk * gpb + within % gpb] = g;
+    // descending: bin 0 holds the longest rests
+    auto bin_of = [&](uint32_t rest) -> uint32_t { return 2047u - (uint32_t)(((unsigned long long)rest * 2047ull) / (unsigned long long)T_); };
+    for (int pass = have_pool ? 0 : 1; pass < 2; pass++) {
+        // pass 0: the pool (boundaries with a rest); pass 1: the permutation (every interval g by the rest of boundary g + 1)
+        for (int b = t; b < 2048; b += 1024) bins[b] = 0u;
+        __syncthreads();
+        for (int g = t; g < m; g += 1024) {
+            const uint32_t r = rest_of(pass == 0 ? g : g + 1);
+            if (pass == 1 || r > 0u) atomicAdd(&bins[bin_of(r)], 1u);
+        }
+        __syncthreads();
+        if (t == 0) { uint32_t a = 0; for (int b = 0; b < 2048; b++) { const uint32_t v = bins[b]; bins[b] = a; a += v; } if (pass == 0) L.mig_late[1] = (int)a; }
+        __syncthreads();
+        const int gpb = m / (2 * L.num_cus) > 0 ? m / (2 * L.num_cus) : 1, half = L.num_cus;     // lane groups per workgroup; workgroups per half of the grid
+        for (int g = t; g < m; g += 1024) {
+            const uint32_t r = rest_of(pass == 0 ? g : g + 1);
+            if (pass == 0) { if (r > 0u) L.mig_late[2 + atomicAdd(&bins[bin_of(r)], 1u)] = g; continue; }
+            if (L.mig_identity || m != 2 * L.num_cus * gpb) { L.mig_perm[g] = g; continue; }
+            const uint32_t u = atomicAdd(&bins[bin_of(r)], 1u);       // rank of interval g
+            // rank u -> physical lane group: CU u / (2 gpb), its first workgroup for the first gpb ranks, its second for the rest
+            const int cu = (int)(u / (uint32_t)(2 * gpb)), within = (int)(u % (uint32_t)(2 * gpb));
+            const int blk = within < gpb ? cu : cu + half;
+            L.mig_perm[blk * gpb + within % gpb] = g;
+        }
+        __syncthreads();
     }
 }
 

@@ -54,10 +54,11 @@ DebugOption g_opts[] = {
     {"static_ck", "AGATHA_AMD_STATIC_CK", {1}},   // int16 kernel, static schedule, three register pairs per lane: 1 = checkpoints there as well (a pair that must be started over goes back in place), 0 = none (such a pair goes to the int32 kernel behind)
     {"win_cap_min", "AGATHA_AMD_WIN_CAP_MIN", {128}},    // int16 kernel: the adaptive part of the window of key steps at a pair's end is capped at max(win_cap_min, steps of the pair / win_cap_div)
     {"win_cap_div", "AGATHA_AMD_WIN_CAP_DIV", {16}},
+    {"no_pool", "AGATHA_AMD_NO_POOL", {0}},             // static schedule: 1 = every lane group resumes the pair that crosses out of its own interval (until round 4); 0 = the rests of the suspended pairs are a pool, longest first, for whoever is done with its fixed part
     {"mig_identity", "AGATHA_AMD_MIG_IDENTITY", {0}},   // static schedule: 1 = lane group g owns interval g of the line of pairs (until round 4); 0 = intervals whose pairs end together share a wave (schedule_kernel)
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {384}},    // int16 kernel: pairs of at least this many steps take checkpoints (0: none do; 1024 until late in round 4: 3 kb pairs with broken reads among them, 22 -> 19 ms)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -137,7 +138,7 @@ size_t base_workspace_bytes(uint32_t n)
 }
 size_t mig_workspace_bytes(uint32_t n)
 {
-    return round_up(sizeof(uint32_t) * ((size_t)n + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots) +
+    return round_up(sizeof(uint32_t) * ((size_t)n + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 2)) +
            round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords) + agatha::kMigBufBytes;
 }
 
@@ -389,6 +390,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     uint32_t* cum = (uint32_t*)ws;                           ws += round_up(sizeof(uint32_t) * ((size_t)n_alns + 1));
     int* mig_state = (int*)ws;                               ws += round_up(sizeof(int) * (agatha::kMigMaxSlots + 1));
     int* mig_perm = (int*)ws;                                ws += round_up(sizeof(int) * agatha::kMigMaxSlots);
+    int* mig_late = (int*)ws;                                ws += round_up(sizeof(int) * (agatha::kMigMaxSlots + 2));
     uint32_t* timeline = (uint32_t*)ws;                      ws += round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords);
     uint32_t* mig_buf = (uint32_t*)ws;
     // the checkpoint area lies behind everything else (behind the schedule's areas when the workspace holds them)
@@ -442,7 +444,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         HIPCHK(agatha::launch_tb_plan(L, tb_gs, (unsigned long long)(cap / 4), tb_passes, off, pass, plan, st));
     }
     L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;
-    L.mig_slot_dwords = 0; L.mig_fallback = 0; L.mig_perm = nullptr; L.mig_identity = opt(OPT_MIG_IDENTITY) ? 1 : 0;
+    L.mig_slot_dwords = 0; L.mig_fallback = 0; L.mig_perm = nullptr; L.mig_late = nullptr; L.mig_identity = opt(OPT_MIG_IDENTITY) ? 1 : 0;
     L.timeline = nullptr;
     L.simd_steps = simd_steps;
     HIPCHK(hipMemsetAsync(simd_steps, 0, sizeof(int) * agatha::kSimdStepsInts, st));
@@ -495,7 +497,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         if (slots <= agatha::kMigMaxSlots && (size_t)slots * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes) {
             // (room for a second state per boundary: the fallback of a pair that is suspended with a bound for its maximum)
             const bool two = (size_t)slots * 2 * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes;
-            L.mig_enabled = opt(OPT_NO_MIGRATE) < 0 ? 2 : 1; L.mig_slots = slots; L.mig_perm = mig_perm; L.mig_slot_dwords = two ? 2 * dwords : dwords; L.mig_fallback = two ? 1 : 0;
+            L.mig_enabled = opt(OPT_NO_MIGRATE) < 0 ? 2 : 1; L.mig_slots = slots; L.mig_perm = mig_perm; L.mig_late = opt(OPT_NO_POOL) ? nullptr : mig_late; L.mig_slot_dwords = two ? 2 * dwords : dwords; L.mig_fallback = two ? 1 : 0;
             HIPCHK(hipMemsetAsync(mig_state, 0, sizeof(int) * ((size_t)slots + 1), st));
             HIPCHK(agatha::launch_schedule(L, st));
         }
@@ -697,7 +699,7 @@ int agatha_amd_timeline(void* stream, const void* d_workspace, uint32_t n_alns, 
     // the timeline area is part of the schedule's areas: only workspaces sized for more than kMigMinPairs pairs have it
     if (n_alns <= kMigMinPairs) { snprintf(g_err, sizeof(g_err), "agatha_amd_timeline: workspaces for <= %u pairs hold no timeline area", kMigMinPairs); return AGATHA_AMD_EWORKSPACE; }
     const char* ws = (const char*)d_workspace;
-    ws += base_workspace_bytes(n_alns) + round_up(sizeof(uint32_t) * ((size_t)n_alns + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots);
+    ws += base_workspace_bytes(n_alns) + round_up(sizeof(uint32_t) * ((size_t)n_alns + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 2));
     const uint32_t nw = std::min<uint32_t>(max_waves, agatha::kTimelineWaves);
     hipError_t e = hipMemcpyAsync(out, ws, sizeof(uint32_t) * agatha::kTimelineDwords * nw, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);

@@ -51,6 +51,7 @@ struct AlignLaunch {
     int* mig_perm;                 // device: [mig_slots] the interval of the line of pairs each physical lane group owns (schedule_kernel; nullptr: its own index)
     uint32_t* mig_buf;             // device: suspended state of those pairs, mig_slot_dwords per boundary
     int mig_slot_dwords;           // (stride of a boundary's states in mig_buf)
+    int* mig_late;                 // device: the pool of the suspended pairs' rests: [0] head (atomic), [1] how many, [2 ..] the boundaries, longest rest first (schedule_kernel; nullptr: no pool, every lane group resumes the pair that crosses out of its own interval)
     int mig_identity;              // 1: lane group g owns interval g (debug option mig_identity: the schedule without the permutation, A/B runs)
     int mig_fallback;              // 1: the stride holds TWO states, the suspended one and a fallback (the older checkpoint of a pair that was suspended with a bound for its maximum)
     unsigned int mig_timeout_ticks;  // 100 MHz ticks a group waits for a pair that another group is RUNNING to be suspended before it takes the pair over
@@ -92,6 +93,8 @@ enum { MIG_FRESH = 0, MIG_RUNNING = 1, MIG_SAVED = 2, MIG_DONE = 3, MIG_STOLEN =
 constexpr int mig_fields(int P) { return P * 26 + 7 + ((2 * P + 1) * 9 + 1) / 2 + 10; }
 // largest `spread` (how far below an anti-diagonal maximum an in-band cell can be) the packed-int16 kernel is offered for
 constexpr int kAlign16MaxSpread = 16000;
+// ... and the largest scores (agatha16_scores_ok); the kernel's one 32-bit subtract of two packed halves rests on them (align16_block.inc, row_cells8)
+constexpr int kAlign16MaxMatch = 16, kAlign16MaxMismatch = 32, kAlign16MaxGapOpen = 64, kAlign16MaxGapExtend = 16;
 // what a pair costs its lane group beyond its own steps (finding it, loading its lengths and reference words, building the
 // score profiles: ~4 dependent memory round trips), in steps, per lane group of the wave -- every start stalls all the
 // groups of its wave, so a pair costs its group kMigPairOverheadSteps * (64 / G) steps; the schedule counts that, so that

@@ -319,6 +319,7 @@ static void init_col16(lane_t *ln, int s, int r, int R, int prl, int w, int gapo
  * must be the oracle's. */
 __thread int agatha_lanes16_margin = 0;
 int agatha_lanes16_win_cap_min = 128, agatha_lanes16_win_cap_div = 16;     /* the kernel's debug options of the same names */
+int agatha_lanes16_trace = 0;             /* tools: print every step's mode, bound and whether the cell of the maximum is known (stderr) */
 int agatha_lanes16_old_window = 0;        /* tools: round 4's rule for the window of key steps (3/2 (slack + 7 ge) i / best) */
 
 int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_params_t *pr,
@@ -381,7 +382,8 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 const int active = !final && r < prl && q >= cs && q <= ce && r >= ss && r <= se;
                 ln->bhi[s] = INT_MIN; ln->blo[s] = INT_MIN;
                 if (!active) { ln->xr[s + 1] = -2; continue; }
-                if (pq[q] & 0x88888888u) n_in_flight = 1;
+                /* (an N of the query itself: the pair is flagged by exotic_kernel; the N padding behind the query's end does not count) */
+                { const int real = imin(8, Q - 8 * q); if (real > 0 && (pq[q] & 0x88888888u & (real >= 8 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (4 * real))))) n_in_flight = 1; }
                 if (y == 0)
                     for (int m = 0; m < 8; m++) if (8 * r + m >= R) { ln->h[s][m] = L16_NEG; ln->f[s][m] = L16_NEG; }
                 int32_t xh[8], xe[8], xe_in[8];
@@ -574,6 +576,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 if (z >= 0 && best - H > z + l * ge) stopped = 1;
             }
         }
+        if (agatha_lanes16_trace && i >= agatha_lanes16_trace) fprintf(stderr, "step %d of %d fast %d stale %d calm %d best %d pos_known %d ewin %d HI %d base %d\n", i, total, fast, stale, calm, best, pos_known, ewin, HI, base);
         if (bail || stopped || final) break;
         for (int k = 0; k < G; k++) {
             for (int x = 0; x < 7; x++) { L[k].A[x] = L[k].A[8 + x]; L[k].CAR[0][x] = L[k].AV[0][8 + x]; L[k].CAR[1][x] = L[k].AV[1][8 + x]; }
