@@ -566,16 +566,25 @@ schedule_kernel(AlignLaunch L, int GS, int G)
     const bool use_ = L.sched[0] != 0 && T_ > 0;
     if (t == 0 && have_pool) { L.mig_late[0] = 0; L.mig_late[1] = 0; }
     if (!use_) { for (int g = t; g < m; g += 1024) L.mig_perm[g] = g; return; }
-    // rest of the pair across boundary b (0: the boundary falls between two pairs, or b is no boundary)
-    auto rest_of = [&](int b) -> uint32_t {
-        if (b <= 0 || b >= m) return 0u;
-        const uint32_t at = (uint32_t)b * (uint32_t)T_;
-        int lo = 0, hi = n;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.cum[mid + 1] > at) hi = mid; else lo = mid + 1; }
-        if (lo >= n) return 0u;
-        const uint32_t c = L.cum[lo];
-        return c < at ? at - c : 0u;
-    };
+    // rest of the pair across boundary b (0: the boundary falls between two pairs, or b is no boundary), for all b once: thread t takes
+    // the boundaries [t per, (t + 1) per) -- one binary search for the first, a short walk along the line for the others (a boundary lies
+    // about one pair behind the one before) -- and leaves them in L.mig_rest[0 .. m]
+    {
+        const int per = (m + 1 + 1023) / 1024;
+        int j = -1;
+        for (int b = t * per; b < min(m + 1, (t + 1) * per); b++) {
+            uint32_t r = 0u;
+            if (b > 0 && b < m) {
+                const uint32_t at = (uint32_t)b * (uint32_t)T_;
+                if (j < 0) { int lo = 0, hi = n; while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.cum[mid + 1] > at) hi = mid; else lo = mid + 1; } j = lo; }
+                else while (j < n && L.cum[j + 1] <= at) j++;
+                if (j < n) { const uint32_t c = L.cum[j]; r = c < at ? at - c : 0u; }
+            }
+            L.mig_rest[b] = r;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
     // descending: bin 0 holds the longest rests
     auto bin_of = [&](uint32_t rest) -> uint32_t { return 2047u - (uint32_t)(((unsigned long long)rest * 2047ull) / (unsigned long long)T_); };
     for (int pass = have_pool ? 0 : 1; pass < 2; pass++) {
@@ -583,7 +592,7 @@ schedule_kernel(AlignLaunch L, int GS, int G)
         for (int b = t; b < 2048; b += 1024) bins[b] = 0u;
         __syncthreads();
         for (int g = t; g < m; g += 1024) {
-            const uint32_t r = rest_of(pass == 0 ? g : g + 1);
+            const uint32_t r = L.mig_rest[pass == 0 ? g : g + 1];
             if (pass == 1 || r > 0u) atomicAdd(&bins[bin_of(r)], 1u);
         }
         __syncthreads();
@@ -591,7 +600,7 @@ schedule_kernel(AlignLaunch L, int GS, int G)
         __syncthreads();
         const int gpb = m / (2 * L.num_cus) > 0 ? m / (2 * L.num_cus) : 1, half = L.num_cus;     // lane groups per workgroup; workgroups per half of the grid
         for (int g = t; g < m; g += 1024) {
-            const uint32_t r = rest_of(pass == 0 ? g : g + 1);
+            const uint32_t r = L.mig_rest[pass == 0 ? g : g + 1];
             if (pass == 0) { if (r > 0u) L.mig_late[2 + atomicAdd(&bins[bin_of(r)], 1u)] = g; continue; }
             if (L.mig_identity || m != 2 * L.num_cus * gpb) { L.mig_perm[g] = g; continue; }
             const uint32_t u = atomicAdd(&bins[bin_of(r)], 1u);       // rank of interval g

@@ -138,7 +138,7 @@ size_t base_workspace_bytes(uint32_t n)
 }
 size_t mig_workspace_bytes(uint32_t n)
 {
-    return round_up(sizeof(uint32_t) * ((size_t)n + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 2)) +
+    return round_up(sizeof(uint32_t) * ((size_t)n + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots) + round_up(sizeof(int) * (2 * agatha::kMigMaxSlots + 4)) +
            round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords) + agatha::kMigBufBytes;
 }
 
@@ -390,7 +390,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     uint32_t* cum = (uint32_t*)ws;                           ws += round_up(sizeof(uint32_t) * ((size_t)n_alns + 1));
     int* mig_state = (int*)ws;                               ws += round_up(sizeof(int) * (agatha::kMigMaxSlots + 1));
     int* mig_perm = (int*)ws;                                ws += round_up(sizeof(int) * agatha::kMigMaxSlots);
-    int* mig_late = (int*)ws;                                ws += round_up(sizeof(int) * (agatha::kMigMaxSlots + 2));
+    int* mig_late = (int*)ws;                                ws += round_up(sizeof(int) * (2 * agatha::kMigMaxSlots + 4));
     uint32_t* timeline = (uint32_t*)ws;                      ws += round_up(sizeof(uint32_t) * agatha::kTimelineWaves * agatha::kTimelineDwords);
     uint32_t* mig_buf = (uint32_t*)ws;
     // the checkpoint area lies behind everything else (behind the schedule's areas when the workspace holds them)
@@ -444,7 +444,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         HIPCHK(agatha::launch_tb_plan(L, tb_gs, (unsigned long long)(cap / 4), tb_passes, off, pass, plan, st));
     }
     L.mig_enabled = 0; L.mig_slots = 0; L.cum = cum; L.sched = (int*)(queue + 16); L.mig_state = mig_state; L.mig_buf = mig_buf;
-    L.mig_slot_dwords = 0; L.mig_fallback = 0; L.mig_perm = nullptr; L.mig_late = nullptr; L.mig_identity = opt(OPT_MIG_IDENTITY) ? 1 : 0;
+    L.mig_slot_dwords = 0; L.mig_fallback = 0; L.mig_perm = nullptr; L.mig_late = nullptr; L.mig_rest = nullptr; L.mig_identity = opt(OPT_MIG_IDENTITY) ? 1 : 0;
     L.timeline = nullptr;
     L.simd_steps = simd_steps;
     HIPCHK(hipMemsetAsync(simd_steps, 0, sizeof(int) * agatha::kSimdStepsInts, st));
@@ -497,7 +497,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         if (slots <= agatha::kMigMaxSlots && (size_t)slots * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes) {
             // (room for a second state per boundary: the fallback of a pair that is suspended with a bound for its maximum)
             const bool two = (size_t)slots * 2 * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes;
-            L.mig_enabled = opt(OPT_NO_MIGRATE) < 0 ? 2 : 1; L.mig_slots = slots; L.mig_perm = mig_perm; L.mig_late = opt(OPT_NO_POOL) ? nullptr : mig_late; L.mig_slot_dwords = two ? 2 * dwords : dwords; L.mig_fallback = two ? 1 : 0;
+            L.mig_enabled = opt(OPT_NO_MIGRATE) < 0 ? 2 : 1; L.mig_slots = slots; L.mig_perm = mig_perm; L.mig_late = opt(OPT_NO_POOL) ? nullptr : mig_late; L.mig_rest = (uint32_t*)(mig_late + agatha::kMigMaxSlots + 2); L.mig_slot_dwords = two ? 2 * dwords : dwords; L.mig_fallback = two ? 1 : 0;
             HIPCHK(hipMemsetAsync(mig_state, 0, sizeof(int) * ((size_t)slots + 1), st));
             HIPCHK(agatha::launch_schedule(L, st));
         }
@@ -699,7 +699,7 @@ int agatha_amd_timeline(void* stream, const void* d_workspace, uint32_t n_alns, 
     // the timeline area is part of the schedule's areas: only workspaces sized for more than kMigMinPairs pairs have it
     if (n_alns <= kMigMinPairs) { snprintf(g_err, sizeof(g_err), "agatha_amd_timeline: workspaces for <= %u pairs hold no timeline area", kMigMinPairs); return AGATHA_AMD_EWORKSPACE; }
     const char* ws = (const char*)d_workspace;
-    ws += base_workspace_bytes(n_alns) + round_up(sizeof(uint32_t) * ((size_t)n_alns + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 2));
+    ws += base_workspace_bytes(n_alns) + round_up(sizeof(uint32_t) * ((size_t)n_alns + 1)) + round_up(sizeof(int) * (agatha::kMigMaxSlots + 1)) + round_up(sizeof(int) * agatha::kMigMaxSlots) + round_up(sizeof(int) * (2 * agatha::kMigMaxSlots + 4));
     const uint32_t nw = std::min<uint32_t>(max_waves, agatha::kTimelineWaves);
     hipError_t e = hipMemcpyAsync(out, ws, sizeof(uint32_t) * agatha::kTimelineDwords * nw, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);

@@ -52,6 +52,7 @@ struct AlignLaunch {
     uint32_t* mig_buf;             // device: suspended state of those pairs, mig_slot_dwords per boundary
     int mig_slot_dwords;           // (stride of a boundary's states in mig_buf)
     int* mig_late;                 // device: the pool of the suspended pairs' rests: [0] head (atomic), [1] how many, [2 ..] the boundaries, longest rest first (schedule_kernel; nullptr: no pool, every lane group resumes the pair that crosses out of its own interval)
+    uint32_t* mig_rest;            // device: [mig_slots + 1] scratch of schedule_kernel: the rest of the pair across every boundary
     int mig_identity;              // 1: lane group g owns interval g (debug option mig_identity: the schedule without the permutation, A/B runs)
     int mig_fallback;              // 1: the stride holds TWO states, the suspended one and a fallback (the older checkpoint of a pair that was suspended with a bound for its maximum)
     unsigned int mig_timeout_ticks;  // 100 MHz ticks a group waits for a pair that another group is RUNNING to be suspended before it takes the pair over
