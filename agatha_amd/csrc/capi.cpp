@@ -54,11 +54,13 @@ DebugOption g_opts[] = {
     {"static_ck", "AGATHA_AMD_STATIC_CK", {1}},   // int16 kernel, static schedule, three register pairs per lane: 1 = checkpoints there as well (a pair that must be started over goes back in place), 0 = none (such a pair goes to the int32 kernel behind)
     {"win_cap_min", "AGATHA_AMD_WIN_CAP_MIN", {128}},    // int16 kernel: the adaptive part of the window of key steps at a pair's end is capped at max(win_cap_min, steps of the pair / win_cap_div)
     {"win_cap_div", "AGATHA_AMD_WIN_CAP_DIV", {16}},
+    {"flat_detect", "AGATHA_AMD_FLAT_DETECT", {1}},     // int16 kernel: 1 = when most pairs of a batch say (at their 64th..127th step) that their score hardly rises, young pairs start over on key steps and later pairs start on them
+    {"flat_percent", "AGATHA_AMD_FLAT_PERCENT", {15}},  // ... when more than this share of the pairs are flat
     {"no_pool", "AGATHA_AMD_NO_POOL", {0}},             // static schedule: 1 = every lane group resumes the pair that crosses out of its own interval (until round 4); 0 = the rests of the suspended pairs are a pool, longest first, for whoever is done with its fixed part
     {"mig_identity", "AGATHA_AMD_MIG_IDENTITY", {0}},   // static schedule: 1 = lane group g owns interval g of the line of pairs (until round 4); 0 = intervals whose pairs end together share a wave (schedule_kernel)
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {384}},    // int16 kernel: pairs of at least this many steps take checkpoints (0: none do; 1024 until late in round 4: 3 kb pairs with broken reads among them, 22 -> 19 ms)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_FLAT_DETECT, OPT_FLAT_PERCENT, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -459,6 +461,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.mig_fresh_timeout_ticks = 100u * (unsigned)std::max(std::min(opt(OPT_MIG_FRESH_TIMEOUT_US), opt(OPT_MIG_TIMEOUT_US)), 0);
     L.mig_test_delay_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TEST_DELAY_US), 0);
     L.fast_margin = std::max(opt(OPT_FAST_MARGIN), 0);
+    L.flat_detect = opt(OPT_FLAT_DETECT) ? 1 : 0; L.flat_percent = std::max(opt(OPT_FLAT_PERCENT), 0);
     L.win_cap_min = std::max(opt(OPT_WIN_CAP_MIN), 0); L.win_cap_div = std::max(opt(OPT_WIN_CAP_DIV), 1);
     {
         // the window of key steps a pair starts with, before it has shown its own rate of rise (align16_body.inc, widen_window): the steps a
@@ -690,6 +693,17 @@ int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns
     hipError_t e = hipMemcpyAsync(out, ws + 20 * sizeof(unsigned int), 40 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "agatha_amd_step_stats");
+    return 0;
+}
+
+int agatha_amd_flat_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[4])
+{
+    if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
+    const char* ws = (const char*)d_workspace;
+    ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets);
+    hipError_t e = hipMemcpyAsync(out, ws + 60 * sizeof(unsigned int), 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "agatha_amd_flat_stats");
     return 0;
 }
 

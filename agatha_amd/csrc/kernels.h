@@ -72,6 +72,8 @@ struct AlignLaunch {
     int fast_anchor;               // 1: the window of key steps starts before the corner of the shorter sequence (default); 0: before the pair's last step (experiments)
     int static_ck;                 // on a static schedule the three-register-pair shapes: 1 = checkpoints and going back to them in place, 0 = none, a pair that must start over goes to the int32 kernel
     int launch_id;                 // a number per agatha_amd_align call (24 bits are stored with every checkpoint: a slot's content must be this call's)
+    int flat_percent;              // ... when more than this share of the pairs that have said so are flat (debug option flat_percent)
+    int flat_detect;               // packed-int16 kernel: 1 = a batch whose pairs are mostly flat (their score hardly rises) runs on key steps (debug option flat_detect)
     int win_prior;                 // packed-int16 kernel: the adaptive part of the window of key steps a pair STARTS with: what a read with 15 % errors needs at this scoring (capi.cpp)
     int win_cap_min, win_cap_div;  // packed-int16 kernel: the adaptive part of a pair's window of key steps is at most max(win_cap_min, steps / win_cap_div) steps
     int fast_margin;               // packed-int16 kernel: > 0 = value steps (align16_body.inc) except in a pair's last fast_margin steps; 0 = key steps only

@@ -99,6 +99,7 @@ def load_library():
     lib.agatha_amd_pack2_host.restype = C.c_long
     lib.agatha_amd_unpack2.argtypes = [vp, vp, vp, C.c_uint32, vp]
     lib.agatha_amd_step_stats.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint)]
+    lib.agatha_amd_flat_stats.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint)]
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.agatha_amd_free.argtypes = [vp]
     lib.agatha_amd_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -122,7 +123,7 @@ EXPORTS = [
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_workspace_bytes_long", "agatha_amd_pack", "agatha_amd_pack_host",
     "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_starts_scratch_bytes", "agatha_amd_align_starts", "agatha_amd_traceback_pair_bytes",
     "agatha_amd_traceback_scratch_bytes",
-    "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_split_info", "agatha_amd_pack2_host", "agatha_amd_unpack2", "agatha_amd_step_stats", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_split_info", "agatha_amd_pack2_host", "agatha_amd_unpack2", "agatha_amd_step_stats", "agatha_amd_flat_stats", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -410,6 +411,14 @@ class DeviceBatch:
         st = stream if stream is not None else self.eng.stream
         c = (C.c_uint * 40)()
         _chk(lib, lib.agatha_amd_step_stats(st, self.d_ws.ptr, self.n, c))
+        return tuple(int(v) for v in c)
+
+    def flat_stats(self, stream=None):
+        """(pairs that said whether they are flat, flat ones, young pairs started over on key steps, 0) of the int16 kernel's last align()."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        c = (C.c_uint * 4)()
+        _chk(lib, lib.agatha_amd_flat_stats(st, self.d_ws.ptr, self.n, c))
         return tuple(int(v) for v in c)
 
     def timeline(self, stream=None, max_waves=4096):

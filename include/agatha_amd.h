@@ -246,6 +246,12 @@ int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_a
  * Synchronises the stream. */
 int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[40]);
 
+/* Diagnostics: the packed-int16 kernel's look at the batch (round 5; DESIGN.md 3.6, "flat batches"): out[0] = pairs that have said,
+ * between their 64th and 128th step, whether their score rises fast enough for a window of key steps at their end, out[1] = of those,
+ * the ones that are flat (they would need more than four times the window a pair may have), out[2] = young pairs that were
+ * started over on key steps because most of the batch is flat, out[3] = 0.  Synchronises the stream. */
+int agatha_amd_flat_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[4]);
+
 /* Diagnostics (debug option "timeline" = 1, workspace sized for > 4096 pairs): where and when every wave of the packed-int16
  * kernel ran in the last agatha_amd_align() on this workspace.  8 dwords per wave (wave = 4 * workgroup + wave in
  * workgroup): start and end in ticks of the 100 MHz real-time counter, HW_ID, XCC_ID, steps executed, pairs started, 2

@@ -319,6 +319,14 @@ static void init_col16(lane_t *ln, int s, int r, int R, int prl, int w, int gapo
  * must be the oracle's. */
 __thread int agatha_lanes16_margin = 0;
 int agatha_lanes16_win_cap_min = 128, agatha_lanes16_win_cap_div = 16;     /* the kernel's debug options of the same names */
+/* Checkpoints (align16_checkpoint.inc / align16_acquire.inc, the shapes without bookkeeping): with agatha_lanes16_ck_span > 0 the model keeps
+ * the state of every span-th step in two slots, and a pair that gives up goes back to the NEWER one when the bound of its maximum has since
+ * risen by more than a bound can lie above a cell (slack + 14 ge), to the older one otherwise, and runs key steps only from there; if it gives
+ * up again (or has no checkpoint) it starts from its first step.  Return codes of agatha_model_lanes16: 0 = as it came, 1 = bailed out, 2 =
+ * started over from its first step, 3 = went back to a checkpoint, 4 = went back to a checkpoint, gave up again, started over.
+ * agatha_lanes16_ck_counts: [0] pairs that went back to the newer checkpoint, [1] to the older one (tests). */
+int agatha_lanes16_ck_span = 0;
+int agatha_lanes16_ck_counts[2] = {0, 0};
 int agatha_lanes16_trace = 0;             /* tools: print every step's mode, bound and whether the cell of the maximum is known (stderr) */
 int agatha_lanes16_old_window = 0;        /* tools: round 4's rule for the window of key steps (3/2 (slack + 7 ge) i / best) */
 
@@ -327,6 +335,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
 {
     const int margin = agatha_lanes16_margin;
     int pos_known = 1, prev_fast = 0, again = 0;
+    int keys_only = 0, rolled = 0;      /* (checkpoints) the pair went back to one and runs key steps for good */
     const int a = pr->match, b = pr->mismatch, gapoe = pr->gap_open + pr->gap_extend, ge = pr->gap_extend;
     const int gapo = pr->gap_open;
     const int sw = pr->slice_width, z = pr->z_threshold, w = pr->band_width;
@@ -369,7 +378,24 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
 #define REB(v) imax((v) - L16_DELTA, imin((v), L16_LO - 1))   /* only in-band values follow the base (v_pk_max / v_pk_min form of the kernel) */
 #define TRACK(v) do { if ((v) < vmin) vmin = (v); if ((v) > vmax) vmax = (v); } while (0)
 
+    /* (checkpoints) two slots: the state before step c, c a multiple of the span */
+    typedef struct { int valid, i, y, final, cb_prev, ss, se, base, best, best_t, best_q, pos_known, prev_fast, ewin; int64_t lo_prev_abs; lane_t *L; } snap_t;
+    snap_t snap[2]; snap[0].valid = snap[1].valid = 0; snap[0].L = snap[1].L = 0;
+    const int ck_span = margin > 0 ? agatha_lanes16_ck_span : 0;
+#define SNAP_SAVE(sn) do { if (!(sn).L) (sn).L = (lane_t *)malloc(sizeof(lane_t) * (size_t)G); memcpy((sn).L, L, sizeof(lane_t) * (size_t)G); (sn).valid = 1; \
+        (sn).i = i; (sn).y = y; (sn).final = final; (sn).cb_prev = cb_prev; (sn).ss = ss; (sn).se = se; (sn).base = base; (sn).best = best; (sn).best_t = best_t; \
+        (sn).best_q = best_q; (sn).pos_known = pos_known; (sn).prev_fast = prev_fast; (sn).ewin = ewin; (sn).lo_prev_abs = lo_prev_abs; } while (0)
+    /* a pair gives up at step i: the checkpoint it goes back to (the kernel's rule), or -1 */
+#define SNAP_PICK(out) do { (out) = -1; if (ck_span > 0 && !keys_only) { const int c0 = (i / ck_span) * ck_span - ck_span, cN = c0 + ck_span; \
+        const snap_t *sN = &snap[(cN / ck_span) & 1], *sO = &snap[(c0 / ck_span) & 1]; \
+        if (cN >= ck_span && cN < i && sN->valid && sN->i == cN && best - sN->best > slack + 14 * ge) (out) = (cN / ck_span) & 1; \
+        else if (c0 >= ck_span && sO->valid && sO->i == c0) (out) = (c0 / ck_span) & 1; } } while (0)
+#define SNAP_LOAD(sn) do { memcpy(L, (sn).L, sizeof(lane_t) * (size_t)G); i = (sn).i; y = (sn).y; final = (sn).final; cb_prev = (sn).cb_prev; ss = (sn).ss; se = (sn).se; \
+        base = (sn).base; best = (sn).best; best_t = (sn).best_t; best_q = (sn).best_q; pos_known = (sn).pos_known; prev_fast = (sn).prev_fast; ewin = (sn).ewin; \
+        lo_prev_abs = (sn).lo_prev_abs; stopped = 0; bail = 0; keys_only = 1; rolled = 1; } while (0)
+run_again:
     for (;;) {
+        if (ck_span > 0 && !keys_only && i >= ck_span && i % ck_span == 0 && i < ewin) SNAP_SAVE(snap[(i / ck_span) & 1]);
         const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
         int n_in_flight = 0;        /* a block of this step works on a query word that holds an N (or the padding behind the query's end) */
         for (int k = 0; k < G; k++)
@@ -482,9 +508,12 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
          *  more than that: every 64 steps the window is widened by the steps that takes at the pair's rate so far, 3/2 of them) */
         /* (round 5: widen_window of align16_body.inc -- the steps a random walk with the pair's rate of rise and the variance its error
          *  rate implies needs to rise by more than slack + 7 ge except with the probability of a 3.5-sigma event) */
-        if (margin > 0 && i > 0 && (i & 63) == 0 && best > 0 && (agatha_lanes16_old_window || i < ewin)) {
-            const int64_t err4 = imax(4 * i * a - best, 0), pen2 = imax(2 * (a + b), a + 2 * gapoe), X_ = slack + 7 * ge;
-            int64_t more = ((6 * err4 * pen2 + 2 * (int64_t)best * X_) * i) / ((int64_t)best * best);
+        if (margin > 0 && i > 0 && (i & 63) == 0 && (best > 0 || !agatha_lanes16_old_window) && (agatha_lanes16_old_window || i < ewin)) {
+            const int64_t X_ = slack + 7 * ge, pen2 = imax(2 * (a + b), a + 2 * gapoe);
+            /* (`best` without a cell is a bound, up to X above the running maximum: the rate is taken from what is certain) */
+            const int64_t best_ = agatha_lanes16_old_window || pos_known ? best : best - X_;
+            const int64_t err4 = imax(4 * i * a - best_, 0);
+            int64_t more = best_ > 0 ? ((6 * err4 * pen2 + 2 * best_ * X_) * i) / (best_ * best_) : (1 << 30);
             if (agatha_lanes16_old_window) {
                 more = ((int64_t)3 * X_ * i) / (2 * (int64_t)best);
                 ewin = imin(ewin, win_anchor - (int)(more < 4096 ? more : 4096));
@@ -495,7 +524,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
             }
         }
         /* (a wave runs key steps while a pair whose query holds an N has an N row in flight: align16_body.inc, want_keys) */
-        const int fast = margin > 0 && i >= 1 && i < ewin && !n_in_flight;
+        const int fast = margin > 0 && i >= 1 && i < ewin && !n_in_flight && !keys_only;
         int calm = 0, stale = 0;
         int32_t HI = INT_MIN;
         if (margin > 0) {
@@ -521,7 +550,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 const int64_t nb = ub > best ? ub : best, lo_both = lo_abs < lo_prev_abs ? lo_abs : lo_prev_abs;
                 calm = !final && (8 * i + 7 < lim) && LO != INT_MIN && lo_prev_abs != INT_MIN && LO >= L16_LO + spread + L16_DELTA + 7 * ge &&
                        lo_abs >= NEG_INF2 + spread && (z < 0 || nb - lo_both <= z);
-                if (!calm) { again = 1; break; }
+                if (!calm) { int pk; SNAP_PICK(pk); if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) & 1) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); continue; } again = 1; break; }
                 if (ub > best) { best = (int)ub; pos_known = 0; }
                 lo_prev_abs = lo_abs;
             } else {
@@ -546,7 +575,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
                 const int64_t base_i = (int64_t)base - (int64_t)ge * (8 * i + 7);
                 calm = !final && (8 * i + 7 < lim) && lo8 != INT_MIN && lo8 >= L16_LO + spread + L16_DELTA + 7 * ge &&
                        lo8 + base_i >= NEG_INF2 + spread && (z < 0 || imax(best, (int)(mk + base_i)) - (int)(lo8 + base_i) <= z);
-                if (!calm && (stale || !pos_known)) { again = 1; break; }
+                if (!calm && (stale || !pos_known)) { int pk; SNAP_PICK(pk); if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) & 1) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); continue; } again = 1; break; }
             }
             prev_fast = fast;
         }
@@ -618,17 +647,24 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
     }
 #undef TRACK
 #undef REB
-    if (margin > 0 && !bail && !pos_known) again = 1;          /* the pair ends without the cell of its maximum */
+    if (margin > 0 && !bail && !pos_known && !again) {          /* the pair ends without the cell of its maximum */
+        int pk; SNAP_PICK(pk);
+        if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) & 1) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); goto run_again; }
+        again = 1;
+    }
     out3[0] = best; out3[1] = best_q; out3[2] = best_t;
     if (stats) { stats[0] = vmin; stats[1] = vmax; stats[2] = bail ? INT_MIN : gmax; stats[3] = bail ? INT_MAX : rmin; }
-    free(pq); free(L);
+    free(pq); free(L); free(snap[0].L); free(snap[1].L);
+#undef SNAP_SAVE
+#undef SNAP_PICK
+#undef SNAP_LOAD
     if (again && !bail) {           /* started over, on key steps only */
         agatha_lanes16_margin = 0;
         const int rc = agatha_model_lanes16(qs, Q, rs, R, pr, G, S, out3, stats);
         agatha_lanes16_margin = margin;
-        return rc == 0 ? 2 : rc;
+        return rc == 0 ? (rolled ? 4 : 2) : rc;
     }
-    return bail;
+    return bail ? 1 : (rolled ? 3 : 0);
 }
 
 /* kind[k]: 0 = aligned by the int16 model, 1 = ineligible / bailed out (out arrays hold the int32 model's answer),

@@ -91,8 +91,11 @@ def test_the_lane_model_and_the_chip_agree_on_who_is_started_over(eng):
         cap_min.value, cap_div.value = saved
     exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_SLICES, threads=16)
     chip = {}
-    defaults = {k: agatha_amd.get_debug_option(k) for k in ("win_cap_min", "win_cap_div")}
+    defaults = {k: agatha_amd.get_debug_option(k) for k in ("win_cap_min", "win_cap_div", "flat_detect")}
     try:
+        # (flat_detect off: with a cap of 45 steps every pair would need "more than four times the window it may have", and the batch
+        #  would be taken for one whose scores do not rise -- what is counted here are the decisions of single pairs)
+        agatha_amd.set_debug_option("flat_detect", 0)
         for name, (cm, cd) in (("round5", (defaults["win_cap_min"], defaults["win_cap_div"])), ("narrow", (45, 1 << 20))):
             agatha_amd.set_debug_option("win_cap_min", cm); agatha_amd.set_debug_option("win_cap_div", cd)
             _, got, info = _run(eng, qs, ts, **REF)

@@ -1,0 +1,87 @@
+"""CPU: the state machine around the packed-int16 kernel's speculative value steps, driven through every transition
+by the CPU model of the kernel's decisions (oracle/agatha_lanes_model.c, agatha_model_lanes16 with a margin and, new in round 5,
+with checkpoints: agatha_lanes16_ck_span).  On the GPU only the fuzzers reach these paths end to end; here each one is forced and
+its RESULT is compared with the oracle:
+
+    value steps -> window of key steps -> result                                   (kind 0: as it came)
+    a value step is not calm (z-drop in reach on a broken read)    -> gives up
+    the pair ends without the cell of its maximum (window too narrow) -> gives up
+        gives up, no checkpoint yet                   -> starts from its first step on key steps           (kind 2)
+        gives up, bound has risen since the newer checkpoint by > slack + 14 ge -> back to the NEWER one   (kind 3, counts[0])
+        gives up, it has not                          -> back to the OLDER one                              (kind 3, counts[1])
+        goes back, key steps from there never place the maximum -> gives up again -> first step            (kind 4)
+
+What the GPU adds on top of this (suspension and resume between lane groups, the fallback state of a suspended pair) restores
+states of the SAME computation; tests/test_gpu_int16.py and tools/gpu_fuzz_mig.py cover those on the chip."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from agatha_amd import workload as W
+
+
+def _batch(seed, n):
+    rng = np.random.default_rng(seed)
+    qs, ts = W.make_pairs(seed, n, lambda r: int(r.integers(600, 4000)), 0.03, 0.03, 0.04)
+    out = []
+    for t in ts:
+        a = np.frombuffer(t, np.uint8).copy()
+        if rng.random() < 0.33:         # a third of the reads: an unrelated tail from a random point on (z-drop ends them there)
+            h = int(rng.integers(len(a) // 10, len(a)))
+            a[h:] = W.random_seq(rng, len(a) - h)
+        out.append(a.tobytes())
+    return O.make_batch(qs), O.make_batch(out)
+
+
+@pytest.fixture()
+def knobs():
+    lib = O.lib()
+    k = dict(span=C.c_int.in_dll(lib, "agatha_lanes16_ck_span"), counts=(C.c_int * 2).in_dll(lib, "agatha_lanes16_ck_counts"),
+             cap_min=C.c_int.in_dll(lib, "agatha_lanes16_win_cap_min"), cap_div=C.c_int.in_dll(lib, "agatha_lanes16_win_cap_div"))
+    saved = (k["span"].value, k["cap_min"].value, k["cap_div"].value)
+    yield k
+    k["span"].value, k["cap_min"].value, k["cap_div"].value = saved
+    k["counts"][0] = k["counts"][1] = 0
+
+
+@pytest.mark.parametrize("scoring", [dict(m=1, x=4, q=6, r=2, z=400), dict(m=2, x=4, q=4, r=2, z=400), dict(m=1, x=4, q=6, r=2, z=-1)])
+def test_every_transition_gives_the_oracles_result(knobs, scoring):
+    (qb, qo, ql), (tb, to, tl) = _batch(11, 220)
+    p = O.make_params(**scoring)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=8)
+    seen = np.zeros(6, np.int64)
+    newer = older = 0
+    # (no checkpoints; a checkpoint every 64 / 128 steps; the window as it is / capped at 24 steps so that pairs end without the cell)
+    for span, cap in ((0, (128, 16)), (64, (128, 16)), (64, (24, 1 << 20)), (128, (24, 1 << 20))):
+        knobs["span"].value = span
+        knobs["cap_min"].value, knobs["cap_div"].value = cap
+        knobs["counts"][0] = knobs["counts"][1] = 0
+        got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, 16, 6, threads=8, value_step_margin=12)
+        for g, e in zip(got[:3], exp):
+            bad = np.nonzero(np.asarray(g) != np.asarray(e))[0]
+            assert bad.size == 0, (scoring, span, cap, bad[:4], got[3][bad[:4]])
+        kinds = np.bincount(got[3] + 1, minlength=6)
+        assert kinds[0] == 0 and kinds[2] == 0                      # nothing refused, nothing left to the int32 model
+        if span == 0:
+            assert kinds[4] == 0 and kinds[5] == 0                  # no checkpoints: a pair that gives up starts from its first step
+        seen += kinds
+        newer += knobs["counts"][0]; older += knobs["counts"][1]
+    # every transition was taken by some pair of some run
+    assert seen[1] > 0 and seen[3] > 0 and seen[4] > 0, seen        # as it came / from its first step / back to a checkpoint
+    assert older > 0
+    if scoring["z"] >= 0 or scoring["m"] == 1:
+        assert seen[5] > 0, seen                                    # went back, gave up again, started over
+
+
+def test_both_checkpoint_rules_are_exercised(knobs):
+    (qb, qo, ql), (tb, to, tl) = _batch(12, 160)
+    p = O.make_params(m=1, x=4, q=6, r=2, z=400)
+    knobs["span"].value = 128
+    knobs["cap_min"].value, knobs["cap_div"].value = 24, 1 << 20
+    knobs["counts"][0] = knobs["counts"][1] = 0
+    got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, 16, 6, threads=8, value_step_margin=12)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=8)
+    assert all((np.asarray(g) == np.asarray(e)).all() for g, e in zip(got[:3], exp))
+    assert knobs["counts"][0] > 0 and knobs["counts"][1] > 0, list(knobs["counts"])      # the newer and the older checkpoint

@@ -97,6 +97,21 @@ def time_pipeline(qs, ts, scoring, w, z, kernel_gcups=None, batch=8192, batches=
             runs.append(dict(host_threads=n_threads, host_packed=packed, storages=2 * n_threads, batches=int(nb), pairs=int(pairs),
                              loop_s=sec, process_wall_s=wall, end_to_end_gcups=gc,
                              vs_kernel_only=(gc / kernel_gcups) if kernel_gcups else None))
+        # The loop's seconds hold the ramp of the FIRST batch (its host fill and H2D: ~20 ms before the first kernel starts -- 6 % of a
+        # 16-batch run, profiles/r05_v1/pipeline_kernel_trace.txt) and the drain of the last one.  The steady state is what a longer feed
+        # adds per batch: the best configuration once more with three times the batches, (t3 - t1) / (2 x batches).
+        best0 = max(runs, key=lambda x: x["end_to_end_gcups"])
+        stats = os.path.join(d, "loop.txt")
+        if os.path.exists(stats):
+            os.remove(stats)
+        cmd = [MANUAL] + (["-K"] if best0["host_packed"] == 2 else ["-k"] if best0["host_packed"] else []) + base + ["-n", str(best0["host_threads"]), ref_fa, query_fa]
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, env=dict(os.environ, AGATHA_AMD_REPEAT=str(3 * rep), AGATHA_AMD_LOOP_STATS=stats))
+        sec3 = float(open(stats).read().split()[0])
+        steady = None
+        if sec3 > best0["loop_s"]:
+            gc_ss = cells_file * 2 * rep / (sec3 - best0["loop_s"]) / 1e9
+            steady = dict(batches=3 * batches, loop_s=sec3, marginal_gcups=gc_ss, vs_kernel_only=(gc_ss / kernel_gcups) if kernel_gcups else None,
+                          ramp_and_drain_ms=1e3 * (best0["loop_s"] - (sec3 - best0["loop_s"]) / 2.0))
         # -p once: per-batch kernel milliseconds + taken-over counts of a sustained run (2 threads, host ASCII)
         r = run_cli(ref_fa, query_fa, scoring, w, z, batch, 2, d)       # (one pass over the file: 2 batches per thread-pair)
         taken = r["pairs_taken_over"]
@@ -112,7 +127,7 @@ def time_pipeline(qs, ts, scoring, w, z, kernel_gcups=None, batch=8192, batches=
     return dict(protocol="agatha_amd/manual (no -p), AGATHA_AMD_REPEAT: %d batches of %d pairs through gasal_aln_async, 2 storages per host thread; "
                          "seconds of the batch loop (host fill + H2D + pack + sort + align + D2H, overlapped)" % (batches, batch),
                 runs=runs, best_end_to_end_gcups=best["end_to_end_gcups"], best_config={k: best[k] for k in ("host_threads", "host_packed")},
-                best_host_packed_vs_kernel_only=(best_k["vs_kernel_only"] if best_k else None),
+                best_host_packed_vs_kernel_only=(best_k["vs_kernel_only"] if best_k else None), steady_state=steady,
                 kernel_ms_per_batch_with_p=kms, pairs_taken_over_with_p=taken)
 
 
