@@ -476,11 +476,15 @@ __global__ void split_gate_kernel(AlignLaunch L)
         if (*L.choice != 0) return;
         while (__hip_atomic_load(L.queue + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && __builtin_amdgcn_s_memrealtime() - t0 < 10000ull)
             __builtin_amdgcn_s_sleep(8);
+        // (what the gate cost this call, in 10 ns ticks: agatha_amd_flat_stats out[3] -- on a runtime that does not run the two streams'
+        //  kernels side by side it is the whole time-out every time, and a regression there should be visible)
+        if (threadIdx.x == 0) L.queue[63] = (unsigned int)(__builtin_amdgcn_s_memrealtime() - t0);
         return;
     }
     while (__hip_atomic_load(L.queue + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_long &&
            __builtin_amdgcn_s_memrealtime() - t0 < 30000ull)
         __builtin_amdgcn_s_sleep(32);
+    if (threadIdx.x == 0) L.queue[63] = (unsigned int)(__builtin_amdgcn_s_memrealtime() - t0);
 }
 
 hipError_t launch_record(const AlignLaunch& L, AlignLaunch* rec, hipStream_t st, const uint32_t* hist, uint32_t nbuckets, int allow_split)

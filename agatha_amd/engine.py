@@ -99,7 +99,8 @@ def load_library():
     lib.agatha_amd_pack2_host.restype = C.c_long
     lib.agatha_amd_unpack2.argtypes = [vp, vp, vp, C.c_uint32, vp]
     lib.agatha_amd_step_stats.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint)]
-    lib.agatha_amd_flat_stats.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint)]
+    if hasattr(lib, "agatha_amd_flat_stats"):        # (developer A/B runs load older builds through AGATHA_AMD_LIB)
+        lib.agatha_amd_flat_stats.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint)]
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.agatha_amd_free.argtypes = [vp]
     lib.agatha_amd_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]

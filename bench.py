@@ -130,7 +130,7 @@ def cpu_baseline(qb, tb, qo, to, ql, tl, scoring, w, budget_s=12.0, gpu_res=None
         scale = float(nom_pp.sum() / max(nom_pp[pick].sum(), 1.0))
         effective = {"effective_cells": float(eff.sum()) * scale, "nominal_cells": float(nom_pp.sum()),
                      "ratio": float(eff.sum() / max(nom_pp[pick].sum(), 1.0)),
-                     "pairs_stopped_early": int((stop < last_d).sum()), "pairs_looked_at": int(len(pick)), "pairs": int(n),
+                     "pairs_stopped_early_of_pairs_looked_at": int((stop < last_d).sum()), "pairs_looked_at": int(len(pick)), "pairs": int(n),
                      "source": f"oracle/ksw_style_avx2.c (+ scalar exact-band model for {nfb} pairs outside int16), every {stride}. pair, "
                                f"{time.time() - t0:.1f} s on {cores} cores; cells of the exact band on the cell anti-diagonals 0..stop"}
     except Exception as e:                  # (the count is an annotation: it must not cost the bench line)

@@ -243,13 +243,16 @@ int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_a
  * step had come, in units of 512 steps, and out[33..37] why the ones beyond 1024 steps had no checkpoint to go back to (second time
  * / pair too short for checkpoints / before its second checkpoint / resumed pair: the state it was resumed from is used / slot
  * overwritten), out[38] = pairs that were suspended with an older checkpoint instead of their present state.
+ * In builds WITHOUT -DAGATHA16_DIAG out[39] = rests of suspended pairs that a lane group took whole from the pool because their first part had
+ * not been started yet (round 5; no work is lost by that, unlike out[14], the pairs taken over after a time-out).
  * Synchronises the stream. */
 int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[40]);
 
 /* Diagnostics: the packed-int16 kernel's look at the batch (round 5; DESIGN.md 3.6, "flat batches"): out[0] = pairs that have said,
  * between their 64th and 128th step, whether their score rises fast enough for a window of key steps at their end, out[1] = of those,
  * the ones that are flat (they would need more than four times the window a pair may have), out[2] = young pairs that were
- * started over on key steps because most of the batch is flat, out[3] = 0.  Synchronises the stream. */
+ * started over on key steps because most of the batch is flat, out[3] = 10 ns ticks the launch of the throughput shape waited behind
+ * the latency shape on the helper stream (split_gate_kernel; 0: no second int16 shape was a candidate).  Synchronises the stream. */
 int agatha_amd_flat_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[4]);
 
 /* Diagnostics (debug option "timeline" = 1, workspace sized for > 4096 pairs): where and when every wave of the packed-int16

@@ -594,7 +594,8 @@ run_again:
                 /* (round 4) only cells that derive from -infinity are left on this anti-diagonal (padded columns behind a short target's
                  * end, rows behind the band's last block): no real anti-diagonal maximum falls from the in-band zone to below L16_LO in
                  * one anti-diagonal, and nothing real follows one that has: the result is final, the pair ends here (align16_body.inc) */
-                if ((v >> K) < L16_LO && pos_known && !stale) { stopped = 1; H = -32768; c = 0; }
+                if ((v >> K) < L16_LO && pos_known && !stale &&
+                    imax(imax(0, d - (R - 1)), (d - w + 1) >> 1) > imin(imin(Q - 1, d), (d + w) >> 1)) { stopped = 1; H = -32768; c = 0; }      /* (... and the geometry agrees: no in-band cell of the pair is left on d) */
                 else
                 if ((v >> K) < L16_LO + spread + L16_DELTA || H < NEG_INF2 + spread) { bail = 1; break; }
             }

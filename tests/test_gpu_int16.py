@@ -464,7 +464,7 @@ def test_a_lane_group_that_never_started_is_taken_over_after_a_short_grace(eng):
             finally:
                 b.free()
         assert sched[0] and _same(got, exp)
-        assert st[14] > 0                   # pairs were taken over ...
+        assert st[14] + st[39] > 0          # pairs were taken over (round 5: a rest whose first part was never started is taken whole at once, out[39]) ...
         assert ms < 45.0, ms                # ... without anybody sitting out the long time-out (30 ms of forced delay + the work)
     finally:
         agatha_amd.set_debug_option("force_choice", -1)
@@ -676,3 +676,29 @@ def test_bands_beyond_1528_run_on_the_int16_kernel(eng, w):
     assert _run_stats.choice[0] == "int16" and _run_stats.choice[1] in (64, 128) and _run_stats.choice[1] * _run_stats.choice[2] >= W + 1
     assert all((g == e).all() for g, e in zip(got, exp))
     assert kinds[2] == 0 and st[0] + st[1] > 0
+
+
+@pytest.mark.parametrize("w", [1500, 2000, 3000])
+def test_z_drop_off_and_sequences_cut_short_on_the_wide_shapes(eng, w):
+    """the early end "an anti-diagonal below the in-band zone ends the pair" must only fire where no in-band cell of the pair
+    is left (round 5: the geometry is checked), also with z-drop off, on very long divergent pairs and on the shapes of round 4 --
+    <64, 2>, <64, 3> as throughput shapes, <128, 1> as the latency shape.  Targets / queries cut to 45 .. 85 % (shorter than the other
+    sequence by more than the band), z = -1 and z = 400, against the oracle; whatever leaves for the int32 kernel comes back right."""
+    rng = np.random.default_rng(w + 7)
+    qs, ts = [], []
+    for k in range(18):
+        ref = WL.random_seq(rng, int(rng.integers(12000, 20000)))
+        rd = WL.mutate(rng, ref, 0.04, 0.04, 0.05)
+        f = float(rng.uniform(0.45, 0.85))
+        if k % 3 == 0:
+            rd = rd[:max(1, int(rd.size * f))]              # target much shorter than the query
+        elif k % 3 == 1:
+            ref = ref[:max(1, int(ref.size * f))]           # query much shorter than the target
+        else:
+            rd = np.concatenate([rd[:int(rd.size * f)], WL.random_seq(rng, rd.size - int(rd.size * f))])      # divergent tail: scores sink
+        qs.append(ref.tobytes()); ts.append(rd.tobytes())
+    for z in (-1, 400):
+        p = dict(BASE, w=w, z=z)
+        got, exp, st, kinds = _run_stats(eng, qs, ts, p, force_int16=1)
+        assert _run_stats.choice[0] == "int16" and _run_stats.choice[1] in (32, 64, 128)
+        assert all((g == e).all() for g, e in zip(got, exp)), (w, z)
