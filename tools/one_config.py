@@ -1,5 +1,5 @@
 """Developer tool (GPU box): one BASELINE workload shape, kernel-only, a few launches (for rocprofv3 --pmc runs).
-    python3 tools/one_config.py C3|C4|C1 [pairs]"""
+    python3 tools/one_config.py C0|C1|C2|C3|C4 [pairs]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import agatha_amd
@@ -7,7 +7,9 @@ from agatha_amd import workload as synth, shard
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 gen, p = {"C3": (lambda n: synth.cfg_c3(n=n or 256), dict(m=2, x=4, q=4, r=2, s=3, z=400, w=1500)),
           "C4": (lambda n: synth.cfg_c4(n=n or 6000), dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)),
-          "C1": (lambda n: synth.cfg_c1(n=n or 10000), dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751))}[name]
+          "C1": (lambda n: synth.cfg_c1(n=n or 10000), dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)),
+          "C0": (lambda n: synth.cfg_c0(n=n or 20000), dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)),
+          "C2": (lambda n: synth.cfg_c2(n=n or 12500), dict(m=2, x=4, q=4, r=2, s=3, z=400, w=500))}[name]
 qs, ts = gen(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 qb, qo, ql = synth.make_batch(qs); tb, to, tl = synth.make_batch(ts)
 cells = int(shard.nominal_cells(ql, tl, p["w"]).sum())
