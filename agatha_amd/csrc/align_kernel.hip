@@ -408,8 +408,10 @@ record_kernel(AlignLaunch L, AlignLaunch* rec, const uint32_t* __restrict__ hist
         const float cost = fmaxf(longest * tl, total * L.cand[c].t_load / (float)L.cand[c].capacity);
         if (cost < bestc) { bestc = cost; best = c; }
     }
+    // (... and only a batch whose longest pair is more than twice its average one can gain by a split: a uniform batch -- the headline
+    //  workload's longest pair is 1.2 x the average -- skips the search over the histogram, 40 us of this one-workgroup kernel)
     const bool can_split = allow_split && hist != nullptr && L.ncand >= 2 && L.cand[0].kind == 1 && L.cand[1].kind == 1 && L.cand[0].G < 64 &&
-                           L.force_choice < 0 && L.n > 64;
+                           L.force_choice < 0 && L.n > 64 && (L.force_split > 0 || longest * (float)L.n > 2.0f * total);
     uint32_t n_long = 0;
     if (can_split) {          // (uniform: every thread takes the branch or none)
         const uint32_t per = (nbuckets + 255u) / 256u;
@@ -525,14 +527,38 @@ schedule_kernel(AlignLaunch L, int GS, int G)
         uint32_t st = (uint32_t)(((total + sw - 1) / sw) * sw + 2 + kMigPairOverheadSteps * (64 / G));
         return st;
     };
+    // (round 5: a pair's step count is looked up once -- three dependent loads -- and parked in cum[j]; the sums over the 1 024 threads are
+    //  a parallel scan, block_scan_1024 below: this one-workgroup kernel stands in front of every align call)
     uint32_t sum = 0, mx = 0, nz = 0;
-    for (int j = j0; j < j1; j++) { const uint32_t p = steps_of(j); sum += p; mx = max(mx, p); nz += p > 1u; }
-    part[t] = sum; pmaxs[t] = mx; nzs[t] = nz;
+    for (int j = j0; j < j1; j++) { const uint32_t p = steps_of(j); L.cum[j] = p; sum += p; mx = max(mx, p); nz += p > 1u; }
+    // exclusive prefix sums of one value per thread (Hillis-Steele over LDS; totals beyond 2^32 are refused below by P < 2^30 --
+    // the 64-bit total comes from a second scan of the high parts' carries: sums of 1 024 values below 2^22 fit 32 bits)
+    auto block_scan_1024 = [&](uint32_t* buf, uint32_t v) -> uint32_t {
+        buf[t] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t add = t >= off ? buf[t - off] : 0u;
+            __syncthreads();
+            buf[t] += add;
+            __syncthreads();
+        }
+        return buf[t] - v;          // exclusive
+    };
+    // (a thread's sum is at most chunk * 2^16 steps; with n <= 16 m <= 2^18 pairs the total stays below 2^34: carried in two halves)
+    const uint32_t ex_lo = block_scan_1024(part, sum & 0xFFFFu), tot_lo = part[1023];
+    __syncthreads();
+    const uint32_t ex_hi = block_scan_1024(part, sum >> 16), tot_hi = part[1023];
+    __syncthreads();
+    const unsigned long long my_ex = (unsigned long long)ex_lo + ((unsigned long long)ex_hi << 16);
+    const unsigned long long total_steps = (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 16);
+    pmaxs[t] = mx; nzs[t] = nz;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) { if (t < off) { pmaxs[t] = max(pmaxs[t], pmaxs[t + off]); nzs[t] += nzs[t + off]; } __syncthreads(); }
+    part[t] = (uint32_t)my_ex;
     __syncthreads();
     if (t == 0) {
-        unsigned long long acc = 0;          // (the 32-bit prefix sums are only used when the total stays below 2^30)
-        uint32_t pm = 0, npairs = 0;
-        for (int k = 0; k < 1024; k++) { const uint32_t v = part[k]; part[k] = (uint32_t)acc; acc += v; pm = max(pm, pmaxs[k]); npairs += nzs[k]; }
+        const unsigned long long acc = total_steps;          // (the 32-bit prefix sums are only used when the total stays below 2^30)
+        const uint32_t pm = pmaxs[0], npairs = nzs[0];
         const long long P = (long long)acc;
         long long T = (P + m - 1) / m; if (T < (long long)pm) T = pm; if (T < 1) T = 1;
         L.cum[n] = (uint32_t)acc;
@@ -549,7 +575,7 @@ schedule_kernel(AlignLaunch L, int GS, int G)
     }
     __syncthreads();
     uint32_t acc = part[t];
-    for (int j = j0; j < j1; j++) { L.cum[j] = acc; acc += steps_of(j); }
+    for (int j = j0; j < j1; j++) { const uint32_t p = L.cum[j]; L.cum[j] = acc; acc += p; }
     // ---- the pool of suspended pairs' rests, and which physical lane group owns which interval (round 5) ----
     // Boundary b T (b = 1 .. m - 1) cuts the pair that lies across it: lane group (interval) b runs its first steps and suspends it; its
     // REST, the L_b = b T - cum[pair] steps before the boundary, is resumed by whoever draws it from the pool: the boundaries sorted by
@@ -600,7 +626,13 @@ schedule_kernel(AlignLaunch L, int GS, int G)
             if (pass == 1 || r > 0u) atomicAdd(&bins[bin_of(r)], 1u);
         }
         __syncthreads();
-        if (t == 0) { uint32_t a = 0; for (int b = 0; b < 2048; b++) { const uint32_t v = bins[b]; bins[b] = a; a += v; } if (pass == 0) L.mig_late[1] = (int)a; }
+        {   // exclusive prefix sums of the 2 048 bins: two per thread
+            const uint32_t b0 = bins[2 * t], b1 = bins[2 * t + 1];
+            __syncthreads();
+            const uint32_t ex = block_scan_1024(part, b0 + b1);
+            bins[2 * t] = ex; bins[2 * t + 1] = ex + b0;
+            if (t == 1023 && pass == 0) L.mig_late[1] = (int)(ex + b0 + b1);
+        }
         __syncthreads();
         const int gpb = m / (2 * L.num_cus) > 0 ? m / (2 * L.num_cus) : 1, half = L.num_cus;     // lane groups per workgroup; workgroups per half of the grid
         for (int g = t; g < m; g += 1024) {
@@ -728,6 +760,8 @@ hipError_t launch_align(const AlignLaunch& L, int window_blocks, int* G_out, int
     }
     if (e != hipSuccess) return e;
     if (two_streams) { e = hipStreamWaitEvent(st, join, 0); if (e != hipSuccess) return e; }
+    // the clean-up launch of the int16 latency shape (pairs of kind 5; returns at once when there is none)
+    if (L.cleanup_ok && L.ncand >= 2 && L.cand[0].kind == 1 && L.cand[1].kind == 1) { e = launch_align16(L, L.cand[1].G, L.cand[1].S / 2, 100, st); if (e != hipSuccess) return e; }
     e = thr->fn(L, 1, kid_thr, st);
     if (e != hipSuccess) return e;
     return thr->fn(L, 2, -1, st);          // compare kernel: walks the queue only if pairs with other letters exist

@@ -56,11 +56,12 @@ DebugOption g_opts[] = {
     {"win_cap_div", "AGATHA_AMD_WIN_CAP_DIV", {16}},
     {"flat_detect", "AGATHA_AMD_FLAT_DETECT", {1}},     // int16 kernel: 1 = when most pairs of a batch say (at their 64th..127th step) that their score hardly rises, young pairs start over on key steps and later pairs start on them
     {"flat_percent", "AGATHA_AMD_FLAT_PERCENT", {15}},  // ... when more than this share of the pairs are flat
+    {"cleanup_min_steps", "AGATHA_AMD_CLEANUP_MIN_STEPS", {384}},   // int16 kernel, static schedule: a pair that must start from its first step at step g of its t steps, 2 g > t + this, goes to the clean-up launch of the latency shape; 0 = it starts over in place (until round 5)
     {"no_pool", "AGATHA_AMD_NO_POOL", {0}},             // static schedule: 1 = every lane group resumes the pair that crosses out of its own interval (until round 4); 0 = the rests of the suspended pairs are a pool, longest first, for whoever is done with its fixed part
     {"mig_identity", "AGATHA_AMD_MIG_IDENTITY", {0}},   // static schedule: 1 = lane group g owns interval g of the line of pairs (until round 4); 0 = intervals whose pairs end together share a wave (schedule_kernel)
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {384}},    // int16 kernel: pairs of at least this many steps take checkpoints (0: none do; 1024 until late in round 4: 3 kb pairs with broken reads among them, 22 -> 19 ms)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_FLAT_DETECT, OPT_FLAT_PERCENT, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_FLAT_DETECT, OPT_FLAT_PERCENT, OPT_CLEANUP_MIN_STEPS, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -495,6 +496,9 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     // (the int16 kernel keeps three flags of a pair in the top bits of its index)
     HIPCHK(agatha::plan_align(L, (int)window, opt(OPT_NO_INT16) != 0 || n_alns >= (1u << 29), opt(OPT_FORCE_INT16) != 0));
     g_last16 = (L.ncand > 0 && L.cand[0].kind == 1) ? ((L.cand[0].G << 8) | L.cand[0].S) : 0;
+    // (the clean-up launch needs an int16 latency shape behind the int16 throughput shape)
+    L.cleanup_min_steps = std::max(opt(OPT_CLEANUP_MIN_STEPS), 0);
+    L.cleanup_ok = (!tb && L.cleanup_min_steps > 0 && L.ncand >= 2 && L.cand[0].kind == 1 && L.cand[1].kind == 1) ? 1 : 0;
     if (mig && L.ncand > 0 && L.cand[0].kind == 1 && L.cand[0].G < 64) {
         const int slots = L.cand[0].capacity, dwords = agatha::align16_mig_fields(L.cand[0].S / 2) * L.cand[0].G;
         if (slots <= agatha::kMigMaxSlots && (size_t)slots * dwords * sizeof(uint32_t) <= agatha::kMigBufBytes) {
@@ -696,12 +700,13 @@ int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns
     return 0;
 }
 
-int agatha_amd_flat_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[4])
+int agatha_amd_flat_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[6])
 {
     if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
     const char* ws = (const char*)d_workspace;
     ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets);
     hipError_t e = hipMemcpyAsync(out, ws + 60 * sizeof(unsigned int), 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out + 4, ws + 14 * sizeof(unsigned int), 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "agatha_amd_flat_stats");
     return 0;
@@ -732,7 +737,7 @@ int agatha_amd_pair_kinds(void* stream, const void* d_workspace, uint32_t n_alns
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { free(h); return hip_fail(e, "agatha_amd_pair_kinds"); }
     counts[0] = counts[1] = counts[2] = 0;
-    for (uint32_t k = 0; k < n_alns; k++) if ((h[k] & 0x7f) < 3) counts[h[k] & 0x7f]++;
+    for (uint32_t k = 0; k < n_alns; k++) { const int kd = (h[k] & 0x7f) == 5 ? 0 : (h[k] & 0x7f); if (kd < 3) counts[kd]++; }      // (5: a plain pair the clean-up launch took)
     free(h);
     return 0;
 }

@@ -24,6 +24,7 @@ struct AlignLaunch {
     uint8_t* exotic;               // per pair kind (low 7 bits; bit 7 = plain pair whose query holds an N): 0 = plain, 1 = holds letters outside ACGTN (compare kernel),
                                    // 2 = abandoned by the packed-int16 kernel (int32 profile kernel takes it),
                                    // 3 = scores out of the kernels' range (no kernel takes it: AGATHA_AMD_BAD_RESULT)
+                                   // 4 = (traceback pass) done by the int16 kernel; 5 = gave up on the static schedule, taken by the clean-up launch of the int16 latency shape
     int ncand;                     // candidates for the kind-0 pairs, in launch order
     KernelChoice cand[4];
     int* choice;                   // device: index of the candidate that takes the kind-0 pairs
@@ -72,6 +73,7 @@ struct AlignLaunch {
     int fast_anchor;               // 1: the window of key steps starts before the corner of the shorter sequence (default); 0: before the pair's last step (experiments)
     int static_ck;                 // on a static schedule the three-register-pair shapes: 1 = checkpoints and going back to them in place, 0 = none, a pair that must start over goes to the int32 kernel
     int launch_id;                 // a number per agatha_amd_align call (24 bits are stored with every checkpoint: a slot's content must be this call's)
+    int cleanup_ok, cleanup_min_steps;   // packed-int16 kernel, static schedule: a pair that must start from its first step at step g of its t, 2 g > t + cleanup_min_steps, leaves for the clean-up launch of the latency shape (kind 5; debug option cleanup_min_steps, 0 = never)
     int flat_percent;              // ... when more than this share of the pairs that have said so are flat (debug option flat_percent)
     int flat_detect;               // packed-int16 kernel: 1 = a batch whose pairs are mostly flat (their score hardly rises) runs on key steps (debug option flat_detect)
     int win_prior;                 // packed-int16 kernel: the adaptive part of the window of key steps a pair STARTS with: what a read with 15 % errors needs at this scoring (capi.cpp)

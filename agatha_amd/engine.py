@@ -415,10 +415,10 @@ class DeviceBatch:
         return tuple(int(v) for v in c)
 
     def flat_stats(self, stream=None):
-        """(pairs that said whether they are flat, flat ones, young pairs started over on key steps, 0) of the int16 kernel's last align()."""
+        """(pairs that said whether they are flat, flat ones, young pairs started over on key steps, gate ticks, pairs sent to the clean-up launch, positions it looked at) of the int16 kernel's last align()."""
         lib = self.eng.lib
         st = stream if stream is not None else self.eng.stream
-        c = (C.c_uint * 4)()
+        c = (C.c_uint * 6)()
         _chk(lib, lib.agatha_amd_flat_stats(st, self.d_ws.ptr, self.n, c))
         return tuple(int(v) for v in c)
 

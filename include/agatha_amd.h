@@ -252,8 +252,10 @@ int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns
  * between their 64th and 128th step, whether their score rises fast enough for a window of key steps at their end, out[1] = of those,
  * the ones that are flat (they would need more than four times the window a pair may have), out[2] = young pairs that were
  * started over on key steps because most of the batch is flat, out[3] = 10 ns ticks the launch of the throughput shape waited behind
- * the latency shape on the helper stream (split_gate_kernel; 0: no second int16 shape was a candidate).  Synchronises the stream. */
-int agatha_amd_flat_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[4]);
+ * the latency shape on the helper stream (split_gate_kernel; 0: no second int16 shape was a candidate), out[4] = pairs that gave up far into
+ * their steps on a static schedule and were aligned by the clean-up launch of the latency shape instead of starting over in place (debug
+ * option cleanup_min_steps), out[5] = positions of the sorted order that launch looked at.  Synchronises the stream. */
+int agatha_amd_flat_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[6]);
 
 /* Diagnostics (debug option "timeline" = 1, workspace sized for > 4096 pairs): where and when every wave of the packed-int16
  * kernel ran in the last agatha_amd_align() on this workspace.  8 dwords per wave (wave = 4 * workgroup + wave in

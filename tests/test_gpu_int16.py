@@ -514,6 +514,8 @@ def _run_stats(eng, qs, ts, p, **opts):
             got = [b.res_host[j].copy() for j in range(3)]
             st, kinds = b.step_stats(), b.pair_kinds()
             _run_stats.choice = b.kernel_choice()
+            _run_stats.flat = b.flat_stats()
+            _run_stats.sched = b.schedule_info()
         finally:
             b.free()
     return got, exp, st, kinds
@@ -702,3 +704,25 @@ def test_z_drop_off_and_sequences_cut_short_on_the_wide_shapes(eng, w):
         got, exp, st, kinds = _run_stats(eng, qs, ts, p, force_int16=1)
         assert _run_stats.choice[0] == "int16" and _run_stats.choice[1] in (32, 64, 128)
         assert all((g == e).all() for g, e in zip(got, exp)), (w, z)
+
+
+def test_pairs_that_give_up_late_on_the_static_schedule_go_to_the_clean_up_launch(eng):
+    """Round 5: on a static schedule a pair that must start from its FIRST step far into its steps costs its lane group a whole pair's key
+    steps that nobody else can take, and the kernel -- which ends with its last wave -- 25 ms for ONE such pair.  It now leaves for a
+    clean-up launch of the int16 latency shape behind the kernel (kind 5: one pair per wave, key steps only).  Forced here: 9 000 pairs
+    of 1 050+ steps, a third of them broken, and no checkpoints at all (ck_min_steps beyond every pair), so that every pair that
+    gives up has nowhere to go back to.  Results = the oracle's with the clean-up launch and without it (cleanup_min_steps = 0: in
+    place, as until round 5); with it the pairs are counted, and they are still 'plain' pairs for agatha_amd_pair_kinds."""
+    qs, ts = _broken_batch(93, 9000, 4200, 5200)
+    p = dict(m=2, x=4, q=4, r=2, s=3, z=400, w=751)
+    # (force_int16 = 0 -- this module's engine sets it --: the clean-up launch is the int16 LATENCY shape, which is only a candidate when the
+    #  device has the choice)
+    got, exp, st, kinds = _run_stats(eng, qs, ts, p, force_int16=0, ck_min_steps=1 << 20, flat_detect=0)
+    assert _run_stats.choice[0] == "int16" and _run_stats.sched[0]      # the int16 throughput shape on the static schedule
+    assert all((g == e).all() for g, e in zip(got, exp))
+    sent = _run_stats.flat[4]
+    assert sent > 50, (sent, st[:4])                                    # broken pairs far into their steps: to the clean-up launch
+    assert kinds[0] == len(qs) - kinds[2] and kinds[2] < 20             # they stay plain pairs
+    got2, exp2, st2, _ = _run_stats(eng, qs, ts, p, force_int16=0, ck_min_steps=1 << 20, flat_detect=0, cleanup_min_steps=0)
+    assert all((g == e).all() for g, e in zip(got2, exp2))
+    assert _run_stats.flat[4] == 0 and st2[2] >= sent                   # in place: nothing sent, at least as many started over

@@ -34,7 +34,7 @@ if os.path.exists(b):
 m = summary.get(short, {})
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     json.dump({"source": f"profiles/{dest} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1, {pairs} pairs)",
-               "kernel": short, "pairs": pairs, "config": "C1",
+               "kernel": short, "pairs": pairs, "config": "C1", "scoring": "m2x4q4r2",
                "preemptive_schedule": bool(json.load(open(b)).get("config", {}).get("preemptive_schedule_rank0", {}).get("used", False)) if os.path.exists(b) else False,
                "hbm_bytes_per_launch": (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024,
                "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"],
