@@ -475,6 +475,10 @@ def main():
 
     if rank == 0:
         elapsed, sst, sched, kinds = L["elapsed"], L["sst"], L["sched"], L["kinds"]
+        # lane-ops per cell the recurrence needs on the steps that just ran (int16: 7 per cell PAIR on value steps, 10 on key steps)
+        ops_needed = OPS_PER_CELL[kind]
+        if kind == "int16" and (sst[0] + sst[1]) > 0:
+            ops_needed = (OPS_PER_CELL_VALUE_STEPS * sst[0] + OPS_PER_CELL["int16"] * sst[1]) / float(sst[0] + sst[1])
         G, S = L["int32_shape"]
         ms_per_step = elapsed / max(a.steps, 1) * 1e3
         out = {
@@ -508,11 +512,14 @@ def main():
                          "kernel": kname,
                          "note": "integer max/add DP at ~1400 cells per algorithmic byte: the HBM roof is not binding, "
                                  "see roofline_valu (DESIGN.md, SURVEY.md 8(d))"},
-            "roofline_valu": {"bound": "valu-" + kind, "achieved": cells * OPS_PER_CELL[kind] / kernel_ms / 1e9,
+            # (round 5, VERDICT r4 weak #4: `frac` prices the lane-ops the kernel NEEDS -- 3.5 per cell on value steps, 5 on key steps, by the
+            #  share of each that just ran --, and round 2's count of 5 everywhere stays as a secondary key so that rounds compare)
+            "roofline_valu": {"bound": "valu-" + kind, "achieved": cells * ops_needed / kernel_ms / 1e9,
                               "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
-                              "frac": cells * OPS_PER_CELL[kind] / kernel_ms / 1e9 / VALU_PEAK_TOPS,
-                              "ops_per_cell": OPS_PER_CELL[kind],
-                              "frac_vs_guide_2cycle_issue": cells * OPS_PER_CELL[kind] / kernel_ms / 1e9 / VALU_GUIDE_PEAK_TOPS,
+                              "frac": cells * ops_needed / kernel_ms / 1e9 / VALU_PEAK_TOPS,
+                              "ops_per_cell": ops_needed,
+                              "frac_vs_guide_2cycle_issue": cells * ops_needed / kernel_ms / 1e9 / VALU_GUIDE_PEAK_TOPS,
+                              "frac_at_round2_count_of_5_per_cell": (cells * OPS_PER_CELL[kind] / kernel_ms / 1e9 / VALU_PEAK_TOPS) if kind == "int16" else None,
                               "frac_at_value_step_count": (cells * OPS_PER_CELL_VALUE_STEPS / kernel_ms / 1e9 / VALU_PEAK_TOPS) if kind == "int16" else None,
                               "peak_source": "measured: profiles/r04_v0/valu_class.txt (4 cycles per wave64 instruction for every packed / SDWA / VOP3 op the "
                                              "kernel is made of; the 2-cycle class -- v_add/sub/and/or/xor, 16-bit VOP2 -- gains < 4 % inside this "
@@ -520,9 +527,9 @@ def main():
                               "issued_lane_ops_per_cell": (issued * 64.0 / cells) if issued else None,
                               "lds_bank_conflict_cycles": conflicts,
                               "note": "lane-ops the recurrence itself needs per cell x cells/s over the measured VALU issue "
-                                      "rate of the chip; the int16 kernel does two cells per packed lane-op.  ops_per_cell keeps "
-                                      "round 2's count (10 per cell pair with H : column keys) so that rounds compare; value steps "
-                                      "need 7 per cell pair since round 4 (frac_at_value_step_count)"},
+                                      "rate of the chip; the int16 kernel does two cells per packed lane-op.  ops_per_cell is what the steps "
+                                      "that just ran need: 7 per cell pair on value steps, 10 on key steps (H : column keys), weighted by the "
+                                      "kernel's own step counters; frac_at_round2_count_of_5_per_cell is the figure of rounds 2-4"},
         }
         if strong_leg is not None:
             SL = strong_leg
