@@ -55,7 +55,7 @@ DebugOption g_opts[] = {
     {"win_cap_min", "AGATHA_AMD_WIN_CAP_MIN", {128}},    // int16 kernel: the adaptive part of the window of key steps at a pair's end is capped at max(win_cap_min, steps of the pair / win_cap_div)
     {"win_cap_div", "AGATHA_AMD_WIN_CAP_DIV", {16}},
     {"flat_detect", "AGATHA_AMD_FLAT_DETECT", {1}},     // int16 kernel: 1 = when most pairs of a batch say (at their 64th..127th step) that their score hardly rises, young pairs start over on key steps and later pairs start on them
-    {"flat_percent", "AGATHA_AMD_FLAT_PERCENT", {15}},  // ... when more than this share of the pairs are flat
+    {"flat_percent", "AGATHA_AMD_FLAT_PERCENT", {30}},  // ... when more than this share of the pairs are flat (clean 10 %-error reads at match 1: 4-8 %; the flat batches of profiles/r05_v1: 49-88 %)
     {"cleanup_min_steps", "AGATHA_AMD_CLEANUP_MIN_STEPS", {384}},   // int16 kernel, static schedule: a pair that must start from its first step at step g of its t steps, 2 g > t + this, goes to the clean-up launch of the latency shape; 0 = it starts over in place (until round 5)
     {"no_pool", "AGATHA_AMD_NO_POOL", {0}},             // static schedule: 1 = every lane group resumes the pair that crosses out of its own interval (until round 4); 0 = the rests of the suspended pairs are a pool, longest first, for whoever is done with its fixed part
     {"mig_identity", "AGATHA_AMD_MIG_IDENTITY", {0}},   // static schedule: 1 = lane group g owns interval g of the line of pairs (until round 4); 0 = intervals whose pairs end together share a wave (schedule_kernel)

@@ -325,6 +325,9 @@ int agatha_lanes16_win_cap_min = 128, agatha_lanes16_win_cap_div = 16;     /* th
  * up again (or has no checkpoint) it starts from its first step.  Return codes of agatha_model_lanes16: 0 = as it came, 1 = bailed out, 2 =
  * started over from its first step, 3 = went back to a checkpoint, 4 = went back to a checkpoint, gave up again, started over.
  * agatha_lanes16_ck_counts: [0] pairs that went back to the newer checkpoint, [1] to the older one (tests). */
+/* (flat batches, align16_body.inc widen_window: a pair says once, at its look between its 64th and 128th step, whether it would need more than
+ * four times the window it may have; the kernel runs a batch on key steps when 30 % of its pairs say so.  The model counts; tools/cliff_sweep.py) */
+int agatha_lanes16_asked = 0, agatha_lanes16_flat = 0;
 int agatha_lanes16_ck_span = 0;
 int agatha_lanes16_ck_counts[2] = {0, 0};
 int agatha_lanes16_trace = 0;             /* tools: print every step's mode, bound and whether the cell of the maximum is known (stderr) */
@@ -520,6 +523,7 @@ run_again:
             } else {
                 /* (what the pair shows of itself may move the window either way while it is still on value steps) */
                 const int64_t cap = imax(agatha_lanes16_win_cap_min, (pql + prl) / imax(agatha_lanes16_win_cap_div, 1));
+                if (i >= 64 && i < 128) { __sync_fetch_and_add(&agatha_lanes16_asked, 1); if (more > 4 * cap) __sync_fetch_and_add(&agatha_lanes16_flat, 1); }
                 ewin = imax(win_anchor - (int)(more < cap ? more : cap), i);
             }
         }

@@ -107,3 +107,43 @@ def test_the_lane_model_and_the_chip_agree_on_who_is_started_over(eng):
     assert model["round5"] <= 8 and chip["round5"] <= 8, (model, chip)
     # (133 and 133 when this was written: the model decides what the kernel decides)
     assert model["narrow"] >= 60 and abs(chip["narrow"] - model["narrow"]) <= max(10, model["narrow"] // 4), (model, chip)
+
+
+def test_a_flat_batch_is_noticed_and_runs_on_key_steps(eng):
+    """Reads whose score hardly rises at the scoring (15 % errors at match 1: the expected gain per base is negative) have no window
+    that holds the last rise of their maximum; half of them used to end without its cell, go back to a checkpoint, fail again and
+    start from their first step (a 10 kb batch: 66 ms against 27 for clean reads, where key steps all along take 35).  The kernel
+    notices: the pairs say at their 64th..127th step whether they are flat, and when 30 % are the young pairs start over on key
+    steps and later pairs start on them.  Here: 9 000 pairs of ~5 kb at 15 % errors on the static schedule -- most say flat, most
+    are restarted young, (almost) nobody fails late, results = the oracle's; the clean batch beside it is left alone."""
+    import agatha_amd
+    qs, ts = synth.make_pairs(77, 9000, lambda r: int(np.clip(np.rint(r.normal(5000, 400)), 4000, 6000)), 0.045, 0.045, 0.06)
+    batch, got, info = _run(eng, qs, ts, **REF)
+    st = info["st"]
+    qb, tb, qo, to, ql, tl = batch
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**REF)); eng.synchronize()
+        flat = b.flat_stats()
+    finally:
+        b.free()
+    assert info["choice"][0] == "int16" and info["sched"][0]
+    assert flat[1] > 0.3 * flat[0] and flat[0] > 4000, flat                # most pairs say: flat
+    assert flat[2] > 4000, flat                                            # ... and the young ones started over on key steps
+    assert st[15] + max(st[2] - flat[2], 0) < 0.03 * len(qs), (st[:16], flat)     # hardly anybody fails late any more
+    assert st[1] > 5 * st[0]                                               # the batch ran on key steps
+    pick = np.sort(np.random.default_rng(8).choice(len(qs), 1200, replace=False))
+    sub = [np.ascontiguousarray(a[pick]) for a in batch[2:]]
+    exp = O.align_batch(batch[0], batch[1], *sub, O.make_params(**REF), wide=True, model=O.MODEL_SLICES, threads=16)
+    assert all((g[pick] == e).all() for g, e in zip(got, exp))
+    # the clean batch of the same shape: nobody is restarted
+    qs2, ts2 = synth.make_pairs(78, 9000, lambda r: int(np.clip(np.rint(r.normal(5000, 400)), 4000, 6000)), 0.03, 0.03, 0.04)
+    batch2, got2, info2 = _run(eng, qs2, ts2, **REF)
+    b = eng.batch(*batch2)
+    try:
+        b.upload(); b.pack(); b.align(agatha_amd.Scores.make(**REF)); eng.synchronize()
+        flat2 = b.flat_stats()
+    finally:
+        b.free()
+    assert flat2[2] == 0 and flat2[1] < 0.2 * max(flat2[0], 1), flat2
+    assert info2["st"][2] + info2["st"][15] <= 9, info2["st"][:16]

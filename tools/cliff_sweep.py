@@ -62,7 +62,11 @@ def run_cell(qs, ts, scoring, band, margin, threads):
     qb, qo, ql = wl.make_batch(qs)
     tb, to, tl = wl.make_batch(ts)
     G, S = shape_gs(band)
+    import ctypes as C
+    asked, flat = C.c_int.in_dll(O.lib(), "agatha_lanes16_asked"), C.c_int.in_dll(O.lib(), "agatha_lanes16_flat")
+    asked.value = flat.value = 0
     got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, G, S, threads=threads, value_step_margin=margin)
+    n_asked, n_flat = asked.value, flat.value
     exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=threads)
     bad = int(sum(1 for k in range(len(ql)) if any(int(got[j][k]) != int(exp[j][k]) for j in range(3))))
     kind = got[3]
@@ -76,7 +80,7 @@ def run_cell(qs, ts, scoring, band, margin, threads):
     zd = st[:, 4] != 0
     over = kind == 2
     return dict(n=len(ql), over=int(over.sum()), over_clean=int((over & ~zd).sum()), back=int((kind == 1).sum()), zdrop=int(zd.sum()),
-                mismatch=bad, ineligible=int((kind == 1).sum()) == len(ql))
+                mismatch=bad, ineligible=int((kind == 1).sum()) == len(ql), asked=n_asked, flat=n_flat)
 
 
 def main():
@@ -105,7 +109,9 @@ def main():
     emit(f"# tools/cliff_sweep.py margin={a.margin} pairs-scale={a.pairs_scale}{' --old-window (round 4 rule)' if a.old_window else ''}: oracle/agatha_lanes_model.c (agatha_model_lanes16), every result checked against the oracle")
     emit("# started over = a value step could not decide / the pair ended without the cell of its maximum (kernel: back to a checkpoint or to its first step, on key steps);")
     emit("# 'clean' = of pairs the oracle does NOT z-drop; handed back = left for the int32 kernel; columns in % of the cell's pairs")
-    emit(f"{'shape':5s} {'scoring':11s} {'err':>4s} {'cut':>5s} {'Nrun':>5s} {'pairs':>5s} {'zdrop%':>7s} {'over%':>7s} {'over-clean%':>11s} {'back%':>6s} {'mismatch':>8s}")
+    emit("# flat% = pairs that say, at their 64th..127th step, that their score hardly rises (of those that were asked); at 30 % the kernel takes the batch for a FLAT one")
+    emit("# and runs it on key steps (1.3-1.4 x its clean batch, profiles/r05_v1/cliff_cells_after.txt): what the model then counts as started over does not happen")
+    emit(f"{'shape':5s} {'scoring':11s} {'err':>4s} {'cut':>5s} {'Nrun':>5s} {'pairs':>5s} {'zdrop%':>7s} {'over%':>7s} {'over-clean%':>11s} {'back%':>6s} {'flat%':>6s} {'mismatch':>8s}")
     t0 = time.time()
     worst = []
     for (sname, lfn, band, npairs), sc, err, cut, nf in itertools.product(shapes, scorings, errors, cuts, nfracs):
@@ -114,11 +120,12 @@ def main():
         qs, ts = make_cell(seed, n, lfn, err, cut, nf)
         r = run_cell(qs, ts, sc, band, a.margin, a.threads)
         pc = lambda v: 100.0 * v / r["n"]
-        emit(f"{sname:5s} {sc[0]:11s} {err:4.2f} {cut:5.2f} {nf:5.2f} {r['n']:5d} {pc(r['zdrop']):7.1f} {pc(r['over']):7.2f} {pc(r['over_clean']):11.2f} {pc(r['back']):6.1f} {r['mismatch']:8d}")
-        worst.append((pc(r["over_clean"]), sname, sc[0], err, cut, nf))
+        flat_pc = 100.0 * r["flat"] / max(r["asked"], 1)
+        emit(f"{sname:5s} {sc[0]:11s} {err:4.2f} {cut:5.2f} {nf:5.2f} {r['n']:5d} {pc(r['zdrop']):7.1f} {pc(r['over']):7.2f} {pc(r['over_clean']):11.2f} {pc(r['back']):6.1f} {flat_pc:6.1f} {r['mismatch']:8d}" + ("  FLAT BATCH" if flat_pc > 30.0 and not a.old_window else ""))
+        worst.append((0.0 if (flat_pc > 30.0 and not a.old_window) else pc(r["over_clean"]), sname, sc[0], err, cut, nf))
         assert r["mismatch"] == 0, "the int16 model disagrees with the oracle"
     worst.sort(reverse=True)
-    emit(f"# {len(worst)} cells in {time.time() - t0:.0f} s; the ten worst by pairs started over although they do not z-drop:")
+    emit(f"# {len(worst)} cells in {time.time() - t0:.0f} s; the ten worst by pairs started over although they do not z-drop (flat batches aside):")
     for w in worst[:10]:
         emit(f"#   {w[0]:6.2f} %  {w[1]} {w[2]} err {w[3]} cut {w[4]} N-run {w[5]}")
     if a.out:
