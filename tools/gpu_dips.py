@@ -12,7 +12,8 @@ RANDOM = os.environ.get("DIPS_RANDOM") == "1"          # the burst is unrelated 
 eng = agatha_amd.Engine(0)
 import os
 CFG = os.environ.get("CFG", "cfg_c1")          # (CFG=cfg_c2 BAND=500: the HiFi shape, two register pairs per lane, checkpoints with bookkeeping)
-sc = agatha_amd.Scores.make(w=int(os.environ.get("BAND", "751")))
+_m, _x, _q, _r = (int(v) for v in os.environ.get("SCORING", "2,4,4,2").split(","))      # (SCORING=1,4,6,2: the reference's bench command)
+sc = agatha_amd.Scores.make(m=_m, x=_x, q=_q, r=_r, w=int(os.environ.get("BAND", "751")))
 qs0, ts0 = getattr(W, CFG)(n=n)
 for burst in ([int(sys.argv[3])] if len(sys.argv) > 3 and sys.argv[3].isdigit() else ([0, 60, 100, 140, 180, 0] if RANDOM else [0, 150, 250, 350, 500, 0])):
     rng = np.random.default_rng(11)

@@ -10,7 +10,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10000
 eng = agatha_amd.Engine(0)
 import os
 CFG = os.environ.get("CFG", "cfg_c1")          # (CFG=cfg_c2 BAND=500: the HiFi shape, two register pairs per lane, checkpoints with bookkeeping)
-sc = agatha_amd.Scores.make(w=int(os.environ.get("BAND", "751")))
+_m, _x, _q, _r = (int(v) for v in os.environ.get("SCORING", "2,4,4,2").split(","))      # (SCORING=1,4,6,2: the reference's bench command)
+sc = agatha_amd.Scores.make(m=_m, x=_x, q=_q, r=_r, w=int(os.environ.get("BAND", "751")))
 qs0, ts0 = getattr(W, CFG)(n=n)
 rng = np.random.default_rng(5)
 for name, fq, ft in (("equal", 1.0, 1.0), ("target 90 %", 1.0, 0.9), ("target 75 %", 1.0, 0.75), ("query 90 %", 0.9, 1.0), ("query 75 %", 0.75, 1.0),
