@@ -57,11 +57,12 @@ DebugOption g_opts[] = {
     {"flat_detect", "AGATHA_AMD_FLAT_DETECT", {1}},     // int16 kernel: 1 = when most pairs of a batch say (at their 64th..127th step) that their score hardly rises, young pairs start over on key steps and later pairs start on them
     {"flat_percent", "AGATHA_AMD_FLAT_PERCENT", {30}},  // ... when more than this share of the pairs are flat (clean 10 %-error reads at match 1: 4-8 %; the flat batches of profiles/r05_v1: 49-88 %)
     {"cleanup_min_steps", "AGATHA_AMD_CLEANUP_MIN_STEPS", {384}},   // int16 kernel, static schedule: a pair that must start from its first step at step g of its t steps, 2 g > t + this, goes to the clean-up launch of the latency shape; 0 = it starts over in place (until round 5)
+    {"probation", "AGATHA_AMD_PROBATION", {1}},         // int16 kernel: 1 = a pair that went back to a checkpoint (or its first step) runs key steps until z-drop is comfortably out of reach again, then value steps and a window; 0 = key steps for good (until round 5)
     {"no_pool", "AGATHA_AMD_NO_POOL", {0}},             // static schedule: 1 = every lane group resumes the pair that crosses out of its own interval (until round 4); 0 = the rests of the suspended pairs are a pool, longest first, for whoever is done with its fixed part
     {"mig_identity", "AGATHA_AMD_MIG_IDENTITY", {0}},   // static schedule: 1 = lane group g owns interval g of the line of pairs (until round 4); 0 = intervals whose pairs end together share a wave (schedule_kernel)
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {384}},    // int16 kernel: pairs of at least this many steps take checkpoints (0: none do; 1024 until late in round 4: 3 kb pairs with broken reads among them, 22 -> 19 ms)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_FLAT_DETECT, OPT_FLAT_PERCENT, OPT_CLEANUP_MIN_STEPS, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_FLAT_DETECT, OPT_FLAT_PERCENT, OPT_CLEANUP_MIN_STEPS, OPT_PROBATION, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -462,6 +463,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.mig_fresh_timeout_ticks = 100u * (unsigned)std::max(std::min(opt(OPT_MIG_FRESH_TIMEOUT_US), opt(OPT_MIG_TIMEOUT_US)), 0);
     L.mig_test_delay_ticks = 100u * (unsigned)std::max(opt(OPT_MIG_TEST_DELAY_US), 0);
     L.fast_margin = std::max(opt(OPT_FAST_MARGIN), 0);
+    L.probation = opt(OPT_PROBATION) ? 1 : 0;
     L.flat_detect = opt(OPT_FLAT_DETECT) ? 1 : 0; L.flat_percent = std::max(opt(OPT_FLAT_PERCENT), 0);
     L.win_cap_min = std::max(opt(OPT_WIN_CAP_MIN), 0); L.win_cap_div = std::max(opt(OPT_WIN_CAP_DIV), 1);
     {
@@ -494,7 +496,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.ck_newer = opt(OPT_CK_NEWER);
     L.choice = choice; L.totals = totals;
     // (the int16 kernel keeps three flags of a pair in the top bits of its index)
-    HIPCHK(agatha::plan_align(L, (int)window, opt(OPT_NO_INT16) != 0 || n_alns >= (1u << 29), opt(OPT_FORCE_INT16) != 0));
+    HIPCHK(agatha::plan_align(L, (int)window, opt(OPT_NO_INT16) != 0 || n_alns >= (1u << 28), opt(OPT_FORCE_INT16) != 0));
     g_last16 = (L.ncand > 0 && L.cand[0].kind == 1) ? ((L.cand[0].G << 8) | L.cand[0].S) : 0;
     // (the clean-up launch needs an int16 latency shape behind the int16 throughput shape)
     L.cleanup_min_steps = std::max(opt(OPT_CLEANUP_MIN_STEPS), 0);

@@ -74,6 +74,7 @@ struct AlignLaunch {
     int static_ck;                 // on a static schedule the three-register-pair shapes: 1 = checkpoints and going back to them in place, 0 = none, a pair that must start over goes to the int32 kernel
     int launch_id;                 // a number per agatha_amd_align call (24 bits are stored with every checkpoint: a slot's content must be this call's)
     int cleanup_ok, cleanup_min_steps;   // packed-int16 kernel, static schedule: a pair that must start from its first step at step g of its t, 2 g > t + cleanup_min_steps, leaves for the clean-up launch of the latency shape (kind 5; debug option cleanup_min_steps, 0 = never)
+    int probation;                 // packed-int16 kernel: 1 = a pair that went back to a checkpoint returns to value steps once z-drop is out of reach again (debug option probation; 0 = key steps for good, until round 5)
     int flat_percent;              // ... when more than this share of the pairs that have said so are flat (debug option flat_percent)
     int flat_detect;               // packed-int16 kernel: 1 = a batch whose pairs are mostly flat (their score hardly rises) runs on key steps (debug option flat_detect)
     int win_prior;                 // packed-int16 kernel: the adaptive part of the window of key steps a pair STARTS with: what a read with 15 % errors needs at this scoring (capi.cpp)

@@ -147,3 +147,42 @@ def test_a_flat_batch_is_noticed_and_runs_on_key_steps(eng):
         b.free()
     assert flat2[2] == 0 and flat2[1] < 0.2 * max(flat2[0], 1), flat2
     assert info2["st"][2] + info2["st"][15] <= 9, info2["st"][:16]
+
+
+def test_a_read_with_a_burst_of_errors_returns_to_value_steps(eng):
+    """A 350-base stretch of 40 % errors in every tenth 10 kb read: at match 1 the score falls by a few hundred inside it, z-drop (400)
+    comes within reach of what a value step knows, the pair goes back to a checkpoint and walks the dip on key steps -- and, round 5,
+    returns to value steps once z-drop is comfortably out of reach again ("probation"; until then it stayed on key steps to its end:
+    34 instead of 27 ms for the batch).  Here: most pairs that go back do return, the batch runs fewer key steps than with the debug
+    option probation = 0, and the results are the oracle's either way."""
+    import agatha_amd
+    qs, ts0 = synth.cfg_c1(n=10000)
+    rng = np.random.default_rng(11)
+    ts, hit = [], []
+    for j, t in enumerate(ts0):
+        if rng.random() < 0.10:
+            a = np.frombuffer(t, np.uint8).copy()
+            at = int(rng.integers(len(a) // 5, len(a) * 4 // 5 - 350))
+            t = np.concatenate([a[:at], synth.mutate(rng, a[at:at + 350], 0.15, 0.12, 0.13), a[at + 350:]]).tobytes()
+            hit.append(j)
+        ts.append(t)
+    runs = {}
+    try:
+        for on in (1, 0):
+            agatha_amd.set_debug_option("probation", on)
+            runs[on] = _run(eng, qs, ts, **REF)
+    finally:
+        agatha_amd.set_debug_option("probation", 1)
+    batch, got, info = runs[1]
+    st, st_off = info["st"], runs[0][2]["st"]
+    assert info["choice"][0] == "int16" and info["sched"][0]
+    assert st[15] > 300 and st_off[15] > 300, (st[:16], st_off[:16])               # hundreds of pairs go back to a checkpoint
+    assert st[13] > 0.5 * st[15] and st_off[13] == 0, (st[:16], st_off[:16])        # ... and most of them leave their probation
+    assert st[1] < 0.85 * st_off[1], (st[:2], st_off[:2])                           # fewer key wave-steps for it
+    r = np.random.default_rng(9)
+    pick = np.sort(np.concatenate([r.choice(np.array(hit), 700, replace=False),
+                                   r.choice(np.setdiff1d(np.arange(10000), np.array(hit)), 500, replace=False)]))
+    sub = [np.ascontiguousarray(a[pick]) for a in batch[2:]]
+    exp = O.align_batch(batch[0], batch[1], *sub, O.make_params(**REF), wide=True, model=O.MODEL_SLICES, threads=16)
+    for on in (1, 0):
+        assert all((g[pick] == e).all() for g, e in zip(runs[on][1], exp)), on
