@@ -245,7 +245,7 @@ int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_a
  * overwritten), out[38] = pairs that were suspended with an older checkpoint instead of their present state.
  * In builds WITHOUT -DAGATHA16_DIAG out[39] = rests of suspended pairs that a lane group took whole from the pool because their first part had
  * not been started yet (round 5; no work is lost by that, unlike out[14], the pairs taken over after a time-out).
- * Likewise out[13] = pairs that, having gone back to a checkpoint or to their first step, returned to value steps (round 5, "probation").
+ * Likewise out[38] = pairs that, having gone back to a checkpoint or to their first step, returned to value steps (round 5, "probation").
  * Synchronises the stream. */
 int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[40]);
 
