@@ -330,6 +330,13 @@ int agatha_lanes16_win_cap_min = 128, agatha_lanes16_win_cap_div = 16;     /* th
 int agatha_lanes16_asked = 0, agatha_lanes16_flat = 0;
 int agatha_lanes16_ck_span = 0;
 int agatha_lanes16_ck_counts[2] = {0, 0};
+/* Probation (round 5, align16_acquire.inc / align16_step_maxima.inc, PROB): with agatha_lanes16_probation = 1 a pair that goes back to a checkpoint
+ * runs key steps from there until 32 steps behind the step it gave up on -- on while z-drop is not out of reach by more than the bounds of
+ * a value step can blur --, then value steps with the window it started with; a pair that gives up ON probation starts from its first step,
+ * on key steps for good.  agatha_lanes16_left_probation counts the pairs' returns to value steps, agatha_lanes16_steps the value / key steps
+ * of everything the model ran (a pair that is run again counts twice: that is what it costs). */
+int agatha_lanes16_probation = 0, agatha_lanes16_left_probation = 0;
+long long agatha_lanes16_steps[2] = {0, 0};
 int agatha_lanes16_trace = 0;             /* tools: print every step's mode, bound and whether the cell of the maximum is known (stderr) */
 int agatha_lanes16_old_window = 0;        /* tools: round 4's rule for the window of key steps (3/2 (slack + 7 ge) i / best) */
 
@@ -339,6 +346,8 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
     const int margin = agatha_lanes16_margin;
     int pos_known = 1, prev_fast = 0, again = 0;
     int keys_only = 0, rolled = 0;      /* (checkpoints) the pair went back to one and runs key steps for good */
+    int prob = 0, prob_until = 0;        /* (probation) ... or until step prob_until, see agatha_lanes16_probation */
+    long long n_value = 0, n_key = 0;
     const int a = pr->match, b = pr->mismatch, gapoe = pr->gap_open + pr->gap_extend, ge = pr->gap_extend;
     const int gapo = pr->gap_open;
     const int sw = pr->slice_width, z = pr->z_threshold, w = pr->band_width;
@@ -373,6 +382,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
         if (mu_ > 0.0) { const double r_ = (sqrt(12.0 * V_) + sqrt(12.0 * V_ + 4.0 * mu_ * (slack + 7 * ge))) / (2.0 * mu_); n_ = r_ * r_ < 4096.0 ? r_ * r_ : 4096.0; }
         ewin = win_anchor - imin((int)ceil(n_), imax(agatha_lanes16_win_cap_min, (pql + prl) / imax(agatha_lanes16_win_cap_div, 1)));
     }
+    const int ewin0 = ewin;             /* (the window a pair starts with: first_window of align16_body.inc) */
     int64_t lo_prev_abs = INT_MIN;      /* value steps: lower bound (absolute score) of the maxima of this step's anti-diagonals 0..6 */
     int best = 0, best_t = 0, best_q = 0, stopped = 0, bail = 0;
     int i = 0, y = 0, final = 0, cb_prev = 0;
@@ -389,16 +399,17 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
         (sn).i = i; (sn).y = y; (sn).final = final; (sn).cb_prev = cb_prev; (sn).ss = ss; (sn).se = se; (sn).base = base; (sn).best = best; (sn).best_t = best_t; \
         (sn).best_q = best_q; (sn).pos_known = pos_known; (sn).prev_fast = prev_fast; (sn).ewin = ewin; (sn).lo_prev_abs = lo_prev_abs; } while (0)
     /* a pair gives up at step i: the checkpoint it goes back to (the kernel's rule), or -1 */
-#define SNAP_PICK(out) do { (out) = -1; if (ck_span > 0 && !keys_only) { const int c0 = (i / ck_span) * ck_span - ck_span, cN = c0 + ck_span; \
+#define SNAP_PICK(out) do { (out) = -1; if (ck_span > 0 && !keys_only && !prob) { const int c0 = (i / ck_span) * ck_span - ck_span, cN = c0 + ck_span; \
         const snap_t *sN = &snap[(cN / ck_span) & 1], *sO = &snap[(c0 / ck_span) & 1]; \
         if (cN >= ck_span && cN < i && sN->valid && sN->i == cN && best - sN->best > slack + 14 * ge) (out) = (cN / ck_span) & 1; \
         else if (c0 >= ck_span && sO->valid && sO->i == c0) (out) = (c0 / ck_span) & 1; } } while (0)
-#define SNAP_LOAD(sn) do { memcpy(L, (sn).L, sizeof(lane_t) * (size_t)G); i = (sn).i; y = (sn).y; final = (sn).final; cb_prev = (sn).cb_prev; ss = (sn).ss; se = (sn).se; \
+#define SNAP_LOAD(sn) do { const int gave_up_at = i; memcpy(L, (sn).L, sizeof(lane_t) * (size_t)G); i = (sn).i; y = (sn).y; final = (sn).final; cb_prev = (sn).cb_prev; ss = (sn).ss; se = (sn).se; \
         base = (sn).base; best = (sn).best; best_t = (sn).best_t; best_q = (sn).best_q; pos_known = (sn).pos_known; prev_fast = (sn).prev_fast; ewin = (sn).ewin; \
-        lo_prev_abs = (sn).lo_prev_abs; stopped = 0; bail = 0; keys_only = 1; rolled = 1; } while (0)
+        lo_prev_abs = (sn).lo_prev_abs; stopped = 0; bail = 0; rolled = 1; \
+        if (agatha_lanes16_probation) { prob = 1; prob_until = gave_up_at + 33; } else keys_only = 1; } while (0)
 run_again:
     for (;;) {
-        if (ck_span > 0 && !keys_only && i >= ck_span && i % ck_span == 0 && i < ewin) SNAP_SAVE(snap[(i / ck_span) & 1]);
+        if (ck_span > 0 && !keys_only && i >= ck_span && i % ck_span == 0 && (prob || i < ewin)) SNAP_SAVE(snap[(i / ck_span) & 1]);
         const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
         int n_in_flight = 0;        /* a block of this step works on a query word that holds an N (or the padding behind the query's end) */
         for (int k = 0; k < G; k++)
@@ -511,7 +522,7 @@ run_again:
          *  more than that: every 64 steps the window is widened by the steps that takes at the pair's rate so far, 3/2 of them) */
         /* (round 5: widen_window of align16_body.inc -- the steps a random walk with the pair's rate of rise and the variance its error
          *  rate implies needs to rise by more than slack + 7 ge except with the probability of a 3.5-sigma event) */
-        if (margin > 0 && i > 0 && (i & 63) == 0 && (best > 0 || !agatha_lanes16_old_window) && (agatha_lanes16_old_window || i < ewin)) {
+        if (margin > 0 && !prob && i > 0 && (i & 63) == 0 && (best > 0 || !agatha_lanes16_old_window) && (agatha_lanes16_old_window || i < ewin)) {
             const int64_t X_ = slack + 7 * ge, pen2 = imax(2 * (a + b), a + 2 * gapoe);
             /* (`best` without a cell is a bound, up to X above the running maximum: the rate is taken from what is certain) */
             const int64_t best_ = agatha_lanes16_old_window || pos_known ? best : best - X_;
@@ -528,7 +539,8 @@ run_again:
             }
         }
         /* (a wave runs key steps while a pair whose query holds an N has an N row in flight: align16_body.inc, want_keys) */
-        const int fast = margin > 0 && i >= 1 && i < ewin && !n_in_flight && !keys_only;
+        const int fast = margin > 0 && i >= 1 && i < ewin && !n_in_flight && !keys_only && !prob;
+        if (fast) n_value++; else n_key++;
         int calm = 0, stale = 0;
         int32_t HI = INT_MIN;
         if (margin > 0) {
@@ -579,6 +591,12 @@ run_again:
                 const int64_t base_i = (int64_t)base - (int64_t)ge * (8 * i + 7);
                 calm = !final && (8 * i + 7 < lim) && lo8 != INT_MIN && lo8 >= L16_LO + spread + L16_DELTA + 7 * ge &&
                        lo8 + base_i >= NEG_INF2 + spread && (z < 0 || imax(best, (int)(mk + base_i)) - (int)(lo8 + base_i) <= z);
+                if (prob) {
+                    /* z-drop out of reach by more than a value step's bounds can blur, and the cell of the maximum known: back to value steps */
+                    const int comfy = calm && pos_known && (z < 0 || imax(best, (int)(mk + base_i)) - (int)(lo8 + base_i) + slack + 14 * ge + 32 <= z);
+                    if (!comfy) prob_until = imax(prob_until, i + 33);
+                    else if (i + 1 >= prob_until) { prob = 0; ewin = ewin0; __sync_fetch_and_add(&agatha_lanes16_left_probation, 1); }
+                }
                 if (!calm && (stale || !pos_known)) { int pk; SNAP_PICK(pk); if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) & 1) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); continue; } again = 1; break; }
             }
             prev_fast = fast;
@@ -657,6 +675,7 @@ run_again:
         if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) & 1) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); goto run_again; }
         again = 1;
     }
+    __sync_fetch_and_add(&agatha_lanes16_steps[0], n_value); __sync_fetch_and_add(&agatha_lanes16_steps[1], n_key);
     out3[0] = best; out3[1] = best_q; out3[2] = best_t;
     if (stats) { stats[0] = vmin; stats[1] = vmax; stats[2] = bail ? INT_MIN : gmax; stats[3] = bail ? INT_MAX : rmin; }
     free(pq); free(L); free(snap[0].L); free(snap[1].L);

@@ -85,3 +85,54 @@ def test_both_checkpoint_rules_are_exercised(knobs):
     exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=8)
     assert all((np.asarray(g) == np.asarray(e)).all() for g, e in zip(got[:3], exp))
     assert knobs["counts"][0] > 0 and knobs["counts"][1] > 0, list(knobs["counts"])      # the newer and the older checkpoint
+
+
+def test_probation_returns_a_pair_to_value_steps_and_changes_no_result(knobs):
+    """Round 5 ("probation"; align16_acquire.inc / align16_step_maxima.inc, PROB): a pair that goes back to a checkpoint runs
+    key steps until 32 steps behind the step it gave up on, on while z-drop is within reach of what a value step can tell, and then returns
+    to value steps; a pair that gives up on probation starts from its first step on key steps for good.  Reads with a 350-base burst of
+    errors at the reference's scoring (match 1: the dip brings z-drop within reach, the read recovers): most pairs go back, most of those
+    return, the key steps of the batch more than halve, and every result is the oracle's -- with probation and without.  Then the
+    broken-read batch of the other tests through every span with probation on: pairs that give up on probation, results the oracle's."""
+    lib = O.lib()
+    prob, left = C.c_int.in_dll(lib, "agatha_lanes16_probation"), C.c_int.in_dll(lib, "agatha_lanes16_left_probation")
+    steps = (C.c_longlong * 2).in_dll(lib, "agatha_lanes16_steps")
+    qs, ts0 = W.make_pairs(5, 48, lambda r: int(r.integers(8000, 12000)), 0.03, 0.03, 0.04)
+    rng = np.random.default_rng(11)
+    ts = []
+    for t in ts0:
+        a = np.frombuffer(t, np.uint8).copy()
+        at = int(rng.integers(len(a) // 5, len(a) * 4 // 5 - 350))
+        ts.append(np.concatenate([a[:at], W.mutate(rng, a[at:at + 350], 0.15, 0.12, 0.13), a[at + 350:]]).tobytes())
+    (qb, qo, ql), (tb, to, tl) = O.make_batch(qs), O.make_batch(ts)
+    p = O.make_params(m=1, x=4, q=6, r=2, z=400, w=751)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=8)
+    knobs["span"].value = 256                      # the kernel's span for pairs of 2 048 .. 4 095 steps
+    seen = {}
+    try:
+        for on in (0, 1):
+            prob.value = on
+            left.value = 0; steps[0] = steps[1] = 0
+            got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, 16, 6, threads=8, value_step_margin=12)
+            assert all((np.asarray(g) == np.asarray(e)).all() for g, e in zip(got[:3], exp)), on
+            seen[on] = (int((got[3] == 3).sum()), left.value, steps[0], steps[1])
+        went_back, returned, _, key_on = seen[1]
+        assert seen[0][0] >= 24 and went_back >= 24, seen             # half the pairs and more go back to a checkpoint
+        assert seen[0][1] == 0 and returned >= went_back // 2, seen   # ... and most of those leave their probation
+        assert key_on < 0.6 * seen[0][3], seen                        # the batch's key steps (62 k -> 27 k when this was written)
+        # broken reads (z-drop ends a third of them): pairs that give up on probation start from their first step; every span, exact
+        (qb, qo, ql), (tb, to, tl) = _batch(11, 220)
+        p = O.make_params(m=1, x=4, q=6, r=2, z=400)
+        exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=8)
+        kinds = np.zeros(6, np.int64)
+        for span, cap in ((64, (128, 16)), (64, (24, 1 << 20)), (128, (24, 1 << 20)), (256, (128, 16))):
+            knobs["span"].value = span
+            knobs["cap_min"].value, knobs["cap_div"].value = cap
+            got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, 16, 6, threads=8, value_step_margin=12)
+            for g, e in zip(got[:3], exp):
+                bad = np.nonzero(np.asarray(g) != np.asarray(e))[0]
+                assert bad.size == 0, (span, cap, bad[:4], got[3][bad[:4]])
+            kinds += np.bincount(got[3] + 1, minlength=6)
+        assert kinds[4] > 0 and kinds[5] > 0, kinds                   # went back (and stayed) / went back, gave up again, started over
+    finally:
+        prob.value = 0

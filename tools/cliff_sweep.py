@@ -11,6 +11,7 @@ and prints, per cell, the share of pairs started over (kind 2), handed to the in
 against the oracle (a mismatch is a bug, not a cliff).  Minutes on 8 cores; no GPU.
 
     python tools/cliff_sweep.py [--pairs-scale 1.0] [--quick] [--out profiles/r05_v1/cliff_sweep.txt] [--margin 12]
+    python tools/cliff_sweep.py --bursts [--shapes C1] [--out profiles/r05_v2/cliff_sweep_bursts.txt]      (reads with a burst of errors; round 5)
 """
 import argparse
 import itertools
@@ -83,6 +84,60 @@ def run_cell(qs, ts, scoring, band, margin, threads):
                 mismatch=bad, ineligible=int((kind == 1).sum()) == len(ql), asked=n_asked, flat=n_flat)
 
 
+def bursts(a):
+    """Reads with a stretch of 40 % errors (tools/gpu_dips.py is the GPU side: profiles/r05_v2/probes_m1_before.txt, probation.txt): the score dips
+    and recovers; where the dip brings z-drop within reach of a value step's bounds the pair goes back to a checkpoint.  Cost of a cell =
+    value steps + 1.4 key steps of everything the model ran (a step run twice counts twice), relative to the same reads without a burst."""
+    import ctypes as C
+    lib = O.lib()
+    span, prob, left = (C.c_int.in_dll(lib, n) for n in ("agatha_lanes16_ck_span", "agatha_lanes16_probation", "agatha_lanes16_left_probation"))
+    steps = (C.c_longlong * 2).in_dll(lib, "agatha_lanes16_steps")
+    lines = []
+
+    def emit(s):
+        print(s, flush=True)
+        lines.append(s)
+
+    emit(f"# tools/cliff_sweep.py --bursts margin={a.margin}: a burst of errors (sub 15 % ins 12 % del 13 %) in EVERY read of a cell, checkpoints as the kernel takes them (every 256 steps),")
+    emit("# probation off / on (DESIGN.md 3.6).  back% = pairs that went back to a checkpoint, ret% = returns to value steps per pair that went back,")
+    emit("# over% = pairs that (also) started from their first step, cost = (value steps + 1.4 key steps) / the same cell without a burst; every result checked against the oracle")
+    emit(f"{'shape':5s} {'scoring':11s} {'burst':>5s} {'pairs':>5s} | {'back%':>6s} {'over%':>6s} {'cost':>6s} | {'back%':>6s} {'ret%':>6s} {'over%':>6s} {'cost':>6s}   (probation off | on)")
+    shapes = [sh for sh in SHAPES if sh[0] in a.shapes.split(",")]
+    for (sname, lfn, band, npairs), sc in itertools.product(shapes, SCORINGS[:3] if not a.quick else SCORINGS[:2]):
+        n = max(8, int(npairs * a.pairs_scale))
+        _, m, x, q, r = sc
+        p = O.make_params(m=m, x=x, q=q, r=r, w=band)
+        G, S = shape_gs(band)
+        base_cost = None
+        for burst in (0, 150, 250, 350, 500):
+            seed = 0xB0857 + zlib.crc32(repr((sname, sc[0])).encode()) % 100000           # (the same reads for every burst length of a row)
+            qs, ts0 = wl.make_pairs(seed, n, lfn, 0.03, 0.03, 0.04)
+            rng = np.random.default_rng(seed + 1)
+            ts = []
+            for t in ts0:
+                arr = np.frombuffer(t, np.uint8).copy()
+                at = int(rng.integers(len(arr) // 5, max(len(arr) // 5 + 1, len(arr) * 4 // 5 - burst)))
+                ts.append(np.concatenate([arr[:at], wl.mutate(rng, arr[at:at + burst], 0.15, 0.12, 0.13), arr[at + burst:]]).tobytes() if burst else t)
+            qb, qo, ql = wl.make_batch(qs)
+            tb, to, tl = wl.make_batch(ts)
+            exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=a.threads)
+            cells = []
+            for on in (0, 1):
+                span.value, prob.value = 256, on
+                left.value = 0; steps[0] = steps[1] = 0
+                got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, G, S, threads=a.threads, value_step_margin=a.margin)
+                span.value = prob.value = 0
+                assert all((np.asarray(g) == np.asarray(e)).all() for g, e in zip(got[:3], exp)), "the int16 model disagrees with the oracle"
+                back, over = int(((got[3] == 3) | (got[3] == 4)).sum()), int(((got[3] == 2) | (got[3] == 4)).sum())
+                cells.append((100.0 * back / n, 100.0 * left.value / max(back, 1), 100.0 * over / n, steps[0] + 1.4 * steps[1]))
+            if burst == 0:
+                base_cost = (cells[0][3], cells[1][3])
+            emit(f"{sname:5s} {sc[0]:11s} {burst:5d} {n:5d} | {cells[0][0]:6.1f} {cells[0][2]:6.1f} {cells[0][3] / base_cost[0]:6.3f} | {cells[1][0]:6.1f} {cells[1][1]:6.1f} {cells[1][2]:6.1f} {cells[1][3] / base_cost[1]:6.3f}")
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        open(a.out, "w").write("\n".join(lines) + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs-scale", type=float, default=1.0)
@@ -92,7 +147,10 @@ def main():
     ap.add_argument("--threads", type=int, default=max(1, len(os.sched_getaffinity(0))))
     ap.add_argument("--shapes", default="C0,C1,C2")
     ap.add_argument("--old-window", action="store_true", help="round 4's rule for the window of key steps (3/2 (slack + 7 ge) i / best, no prior, no cap): the 'before' of round 5")
+    ap.add_argument("--bursts", action="store_true", help="the other table (round 5): reads with a burst of errors (a dip of the score that recovers), with the kernel's checkpoints, probation off and on: who goes back, who returns to value steps, what the batch costs in steps")
     a = ap.parse_args()
+    if a.bursts:
+        return bursts(a)
     if a.old_window:
         import ctypes as C
         C.c_int.in_dll(O.lib(), "agatha_lanes16_old_window").value = 1

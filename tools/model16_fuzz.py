@@ -1,5 +1,5 @@
 """Developer tool (CPU only): randomised check of the int16 kernel's ARITHMETIC MODEL (oracle/agatha_lanes_model.c) against
-the oracle: results, int16 range, zone separation, bail-out rate.  python tools/model16_fuzz.py [trials] [seed]"""
+the oracle: results, int16 range, zone separation, bail-out rate; and of its DECISION model (value steps, checkpoints, probation).  python tools/model16_fuzz.py [trials] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -28,7 +28,20 @@ for t in range(trials):
         bad += 1
         print("MISMATCH trial", t, "w", w, "z", z, "s", s, "scores", (m, x, q, r), "pairs", np.nonzero((e[0] != sc) | (e[1] != qe) | (e[2] != te))[0][:5])
     nb += int((kind == 1).sum()); npairs += len(kind)
+    # the DECISION model on the same batch (value steps with a random margin, checkpoints every 0 / 64 / 128 / 256 steps, probation on or
+    # off -- round 5): whatever a pair goes through, its result is the oracle's
+    import ctypes as C
+    span_, prob_ = C.c_int.in_dll(O.lib(), "agatha_lanes16_ck_span"), C.c_int.in_dll(O.lib(), "agatha_lanes16_probation")
+    span_.value, prob_.value, margin = int(rng.choice([0, 64, 128, 256])), int(rng.integers(0, 2)), int(rng.choice([1, 4, 12, 40]))
+    sc2, qe2, te2, kind2, _ = O.lanes16_batch(qb, tb, qo, to, ql, tl, prm, G, S, threads=8, value_step_margin=margin)
+    if not (np.array_equal(e[0], sc2) and np.array_equal(e[1], qe2) and np.array_equal(e[2], te2)):
+        bad += 1
+        print("MISMATCH (decisions) trial", t, "w", w, "z", z, "s", s, "scores", (m, x, q, r), "span", span_.value, "probation", prob_.value, "margin", margin,
+              "pairs", np.nonzero((e[0] != sc2) | (e[1] != qe2) | (e[2] != te2))[0][:5])
+    kinds_seen = kinds_seen + np.bincount(kind2, minlength=5)[:5] if "kinds_seen" in dir() else np.bincount(kind2, minlength=5)[:5]
+    span_.value = prob_.value = 0
     if (kind == 0).any():
         gmin = min(gmin, st[0]); gmax = max(gmax, st[1]); garb = max(garb, st[2]); rmin = min(rmin, st[3])
 print("trials", trials, "mismatching trials", bad, "pairs", npairs, "bailed", nb)
+print("decision model: pairs as they came / refused / from their first step / back to a checkpoint / back and over again:", [int(v) for v in kinds_seen])
 print("rep range [%d, %d]  largest garbage %d  smallest in-band %d" % (gmin, gmax, garb, rmin))
