@@ -337,6 +337,9 @@ int agatha_lanes16_ck_counts[2] = {0, 0};
  * of everything the model ran (a pair that is run again counts twice: that is what it costs). */
 int agatha_lanes16_probation = 0, agatha_lanes16_left_probation = 0;
 long long agatha_lanes16_steps[2] = {0, 0};
+/* (tools/cliff_sweep.py --bursts: the same two counts per pair, written by agatha_lanes16_batch when the pointer is set -- 2 n entries) */
+long long *agatha_lanes16_pair_steps = 0;
+static __thread long long l16_tl_steps[2];
 int agatha_lanes16_trace = 0;             /* tools: print every step's mode, bound and whether the cell of the maximum is known (stderr) */
 int agatha_lanes16_old_window = 0;        /* tools: round 4's rule for the window of key steps (3/2 (slack + 7 ge) i / best) */
 
@@ -676,6 +679,7 @@ run_again:
         again = 1;
     }
     __sync_fetch_and_add(&agatha_lanes16_steps[0], n_value); __sync_fetch_and_add(&agatha_lanes16_steps[1], n_key);
+    l16_tl_steps[0] += n_value; l16_tl_steps[1] += n_key;
     out3[0] = best; out3[1] = best_q; out3[2] = best_t;
     if (stats) { stats[0] = vmin; stats[1] = vmax; stats[2] = bail ? INT_MIN : gmax; stats[3] = bail ? INT_MAX : rmin; }
     free(pq); free(L); free(snap[0].L); free(snap[1].L);
@@ -707,11 +711,13 @@ void agatha_lanes16_batch(const uint8_t *qbatch, const uint8_t *tbatch, const ui
     for (int k = 0; k < n; k++) {
         int32_t o[3] = {0, 0, 0}, st[4] = {0, 0, INT_MIN, INT_MAX};
         agatha_lanes16_margin = l16_batch_margin;
+        l16_tl_steps[0] = l16_tl_steps[1] = 0;
         int rc = agatha_model_lanes16((const char *)qbatch + qoff[k], (int)qlen[k], (const char *)tbatch + toff[k],
                                       (int)tlen[k], pr, G, S, o, st);
         if (rc == 1) rc = agatha_model_lanes((const char *)qbatch + qoff[k], (int)qlen[k], (const char *)tbatch + toff[k],
                                              (int)tlen[k], pr, G, S, o) != 0 ? -1 : 1;
         kind[k] = rc;
+        if (agatha_lanes16_pair_steps) { agatha_lanes16_pair_steps[2 * k] = l16_tl_steps[0]; agatha_lanes16_pair_steps[2 * k + 1] = l16_tl_steps[1]; }
         score[k] = o[0]; qend[k] = o[1]; tend[k] = o[2];
         if (st[0] < gmin) gmin = st[0];
         if (st[1] > gmax) gmax = st[1];

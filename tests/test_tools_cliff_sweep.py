@@ -29,6 +29,9 @@ def test_bursts_table_shows_pairs_going_back_and_returning():
     cells = [l.replace("|", " ").split() for l in rows[1:]]
     by = {(c[1], int(c[2])): c for c in cells}
     assert float(by[("m2x4q4r2", 350)][4]) == 0.0               # nobody goes back at match 2
-    back_off, back_on, ret = float(by[("m1x4q6r2", 350)][4]), float(by[("m1x4q6r2", 350)][7]), float(by[("m1x4q6r2", 350)][8])
+    back_off, back_on, ret = float(by[("m1x4q6r2", 350)][4]), float(by[("m1x4q6r2", 350)][8]), float(by[("m1x4q6r2", 350)][9])
     assert back_off >= 50.0 and back_on >= 50.0 and ret >= 30.0, by[("m1x4q6r2", 350)]
-    assert float(by[("m1x4q6r2", 350)][10]) < float(by[("m1x4q6r2", 350)][6])          # cost with probation < without
+    row = by[("m1x4q6r2", 350)]                                  # shape scoring burst pairs | back over cost tail | back ret over cost tail
+    assert float(row[11]) < float(row[6])                       # cost with probation < without
+    assert float(row[7]) > 10.0 and float(row[12]) < float(row[7])      # the tail one such pair costs its wave: a cliff; smaller with probation
+    assert float(by[("m2x4q4r2", 350)][7]) < 3.0                # ... and none at match 2

@@ -38,6 +38,9 @@ SHAPES = [("C0", lambda rng: int(np.clip(np.rint(rng.normal(3000, 1000)), 200, 8
           ("C2", lambda rng: int(rng.integers(15000, 20001)), 500, 48)]
 
 
+BENCH_PAIRS = {"C0": 20000, "C1": 10000, "C2": 12500}       # pairs of a bench batch of the shape (bench.py CONFIGS), on 8 192 lane groups of 16 lanes
+
+
 def shape_gs(band):
     """lanes / slots of the int16 throughput shape for this band (align16_kernel.hip: kCfgs16)"""
     win = (band + 7) // 8 + 1
@@ -92,6 +95,7 @@ def bursts(a):
     lib = O.lib()
     span, prob, left = (C.c_int.in_dll(lib, n) for n in ("agatha_lanes16_ck_span", "agatha_lanes16_probation", "agatha_lanes16_left_probation"))
     steps = (C.c_longlong * 2).in_dll(lib, "agatha_lanes16_steps")
+    per_pair = C.c_void_p.in_dll(lib, "agatha_lanes16_pair_steps")
     lines = []
 
     def emit(s):
@@ -101,7 +105,12 @@ def bursts(a):
     emit(f"# tools/cliff_sweep.py --bursts margin={a.margin}: a burst of errors (sub 15 % ins 12 % del 13 %) in EVERY read of a cell, checkpoints as the kernel takes them (every 256 steps),")
     emit("# probation off / on (DESIGN.md 3.6).  back% = pairs that went back to a checkpoint, ret% = returns to value steps per pair that went back,")
     emit("# over% = pairs that (also) started from their first step, cost = (value steps + 1.4 key steps) / the same cell without a burst; every result checked against the oracle")
-    emit(f"{'shape':5s} {'scoring':11s} {'burst':>5s} {'pairs':>5s} | {'back%':>6s} {'over%':>6s} {'cost':>6s} | {'back%':>6s} {'ret%':>6s} {'over%':>6s} {'cost':>6s}   (probation off | on)")
+    emit("# tail% = what ONE such pair costs the wave that holds it on the static schedule, where the kernel ends with its last wave: the steps the pair runs beyond")
+    emit("#   its run without the burst (the way back to the checkpoint, run twice) + 0.4 per key step (the whole wave runs the key form while one pair wants it), worst pair")
+    emit("#   of the cell, over the steps of a lane group (a bench batch of the shape on 8 192 lane groups: 2.4 / 1.2 / 1.5 pairs).  An ESTIMATE: the chip measured + 19 -> + 10 % (250 bases),")
+    emit("#   + 26 -> + 24 % (350), + 11 % (500, C1 at m1 x4 q6 r2 with the burst in every tenth read; profiles/r05_v2/probation.txt) -- the pool of rests takes some of")
+    emit("#   it back, waves with two such pairs add to it.  A cell whose tail% is far from 0 is a cliff on the chip whatever its cost column says.")
+    emit(f"{'shape':5s} {'scoring':11s} {'burst':>5s} {'pairs':>5s} | {'back%':>6s} {'over%':>6s} {'cost':>6s} {'tail%':>6s} | {'back%':>6s} {'ret%':>6s} {'over%':>6s} {'cost':>6s} {'tail%':>6s}   (probation off | on)")
     shapes = [sh for sh in SHAPES if sh[0] in a.shapes.split(",")]
     for (sname, lfn, band, npairs), sc in itertools.product(shapes, SCORINGS[:3] if not a.quick else SCORINGS[:2]):
         n = max(8, int(npairs * a.pairs_scale))
@@ -109,6 +118,7 @@ def bursts(a):
         p = O.make_params(m=m, x=x, q=q, r=r, w=band)
         G, S = shape_gs(band)
         base_cost = None
+        base_pair = None
         for burst in (0, 150, 250, 350, 500):
             seed = 0xB0857 + zlib.crc32(repr((sname, sc[0])).encode()) % 100000           # (the same reads for every burst length of a row)
             qs, ts0 = wl.make_pairs(seed, n, lfn, 0.03, 0.03, 0.04)
@@ -125,14 +135,23 @@ def bursts(a):
             for on in (0, 1):
                 span.value, prob.value = 256, on
                 left.value = 0; steps[0] = steps[1] = 0
+                pp = np.zeros((n, 2), np.int64)
+                per_pair.value = pp.ctypes.data
                 got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, G, S, threads=a.threads, value_step_margin=a.margin)
+                per_pair.value = None
                 span.value = prob.value = 0
                 assert all((np.asarray(g) == np.asarray(e)).all() for g, e in zip(got[:3], exp)), "the int16 model disagrees with the oracle"
                 back, over = int(((got[3] == 3) | (got[3] == 4)).sum()), int(((got[3] == 2) | (got[3] == 4)).sum())
-                cells.append((100.0 * back / n, 100.0 * left.value / max(back, 1), 100.0 * over / n, steps[0] + 1.4 * steps[1]))
+                cells.append([100.0 * back / n, 100.0 * left.value / max(back, 1), 100.0 * over / n, steps[0] + 1.4 * steps[1], pp])
             if burst == 0:
                 base_cost = (cells[0][3], cells[1][3])
-            emit(f"{sname:5s} {sc[0]:11s} {burst:5d} {n:5d} | {cells[0][0]:6.1f} {cells[0][2]:6.1f} {cells[0][3] / base_cost[0]:6.3f} | {cells[1][0]:6.1f} {cells[1][1]:6.1f} {cells[1][2]:6.1f} {cells[1][3] / base_cost[1]:6.3f}")
+                base_pair = (cells[0][4], cells[1][4])
+            tails = []
+            for on in (0, 1):
+                st_, cl_ = cells[on][4], base_pair[on]
+                extra = (st_.sum(1) - cl_.sum(1)) + 0.4 * (st_[:, 1] - cl_[:, 1])
+                tails.append(100.0 * max(float(extra.max()), 0.0) / (BENCH_PAIRS[sname] / 8192.0 * float(cl_.sum(1).mean())))
+            emit(f"{sname:5s} {sc[0]:11s} {burst:5d} {n:5d} | {cells[0][0]:6.1f} {cells[0][2]:6.1f} {cells[0][3] / base_cost[0]:6.3f} {tails[0]:6.1f} | {cells[1][0]:6.1f} {cells[1][1]:6.1f} {cells[1][2]:6.1f} {cells[1][3] / base_cost[1]:6.3f} {tails[1]:6.1f}")
     if a.out:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         open(a.out, "w").write("\n".join(lines) + "\n")
