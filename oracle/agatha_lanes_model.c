@@ -336,6 +336,10 @@ int agatha_lanes16_ck_counts[2] = {0, 0};
  * on key steps for good.  agatha_lanes16_left_probation counts the pairs' returns to value steps, agatha_lanes16_steps the value / key steps
  * of everything the model ran (a pair that is run again counts twice: that is what it costs). */
 int agatha_lanes16_probation = 0, agatha_lanes16_left_probation = 0;
+/* A what-if, not the kernel (tools/cliff_sweep.py --bursts --slots): a RING of agatha_lanes16_ck_slots > 2 checkpoints instead of
+ * the kernel's two.  A pair that gives up goes back to the NEWEST one since which the bound of its maximum has risen by more than slack + 14 ge
+ * (it lies before the last rise: the kernel's rule for the newer of its two), to the oldest one it has otherwise. */
+int agatha_lanes16_ck_slots = 2;
 long long agatha_lanes16_steps[2] = {0, 0};
 /* (tools/cliff_sweep.py --bursts: the same two counts per pair, written by agatha_lanes16_batch when the pointer is set -- 2 n entries) */
 long long *agatha_lanes16_pair_steps = 0;
@@ -396,23 +400,30 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
 
     /* (checkpoints) two slots: the state before step c, c a multiple of the span */
     typedef struct { int valid, i, y, final, cb_prev, ss, se, base, best, best_t, best_q, pos_known, prev_fast, ewin; int64_t lo_prev_abs; lane_t *L; } snap_t;
-    snap_t snap[2]; snap[0].valid = snap[1].valid = 0; snap[0].L = snap[1].L = 0;
+#define L16_MAX_SLOTS 16
+    snap_t snap[L16_MAX_SLOTS];
+    for (int sl = 0; sl < L16_MAX_SLOTS; sl++) { snap[sl].valid = 0; snap[sl].L = 0; }
+    const int nslots = agatha_lanes16_ck_slots > 2 ? imin(agatha_lanes16_ck_slots, L16_MAX_SLOTS) : 2;
     const int ck_span = margin > 0 ? agatha_lanes16_ck_span : 0;
 #define SNAP_SAVE(sn) do { if (!(sn).L) (sn).L = (lane_t *)malloc(sizeof(lane_t) * (size_t)G); memcpy((sn).L, L, sizeof(lane_t) * (size_t)G); (sn).valid = 1; \
         (sn).i = i; (sn).y = y; (sn).final = final; (sn).cb_prev = cb_prev; (sn).ss = ss; (sn).se = se; (sn).base = base; (sn).best = best; (sn).best_t = best_t; \
         (sn).best_q = best_q; (sn).pos_known = pos_known; (sn).prev_fast = prev_fast; (sn).ewin = ewin; (sn).lo_prev_abs = lo_prev_abs; } while (0)
     /* a pair gives up at step i: the checkpoint it goes back to (the kernel's rule), or -1 */
-#define SNAP_PICK(out) do { (out) = -1; if (ck_span > 0 && !keys_only && !prob) { const int c0 = (i / ck_span) * ck_span - ck_span, cN = c0 + ck_span; \
+#define SNAP_PICK(out) do { (out) = -1; if (ck_span > 0 && !keys_only && !prob && nslots == 2) { const int c0 = (i / ck_span) * ck_span - ck_span, cN = c0 + ck_span; \
         const snap_t *sN = &snap[(cN / ck_span) & 1], *sO = &snap[(c0 / ck_span) & 1]; \
         if (cN >= ck_span && cN < i && sN->valid && sN->i == cN && best - sN->best > slack + 14 * ge) (out) = (cN / ck_span) & 1; \
-        else if (c0 >= ck_span && sO->valid && sO->i == c0) (out) = (c0 / ck_span) & 1; } } while (0)
+        else if (c0 >= ck_span && sO->valid && sO->i == c0) (out) = (c0 / ck_span) & 1; } \
+      else if (ck_span > 0 && !keys_only && !prob) { /* (the ring: newest first) */ \
+        for (int kk_ = 0; kk_ < nslots; kk_++) { const int c_ = (i / ck_span) * ck_span - kk_ * ck_span; if (c_ < ck_span) break; if (c_ >= i) continue; \
+            const snap_t *s_ = &snap[(c_ / ck_span) % nslots]; if (!s_->valid || s_->i != c_) continue; \
+            (out) = (c_ / ck_span) % nslots; if (best - s_->best > slack + 14 * ge) break; } } } while (0)
 #define SNAP_LOAD(sn) do { const int gave_up_at = i; memcpy(L, (sn).L, sizeof(lane_t) * (size_t)G); i = (sn).i; y = (sn).y; final = (sn).final; cb_prev = (sn).cb_prev; ss = (sn).ss; se = (sn).se; \
         base = (sn).base; best = (sn).best; best_t = (sn).best_t; best_q = (sn).best_q; pos_known = (sn).pos_known; prev_fast = (sn).prev_fast; ewin = (sn).ewin; \
         lo_prev_abs = (sn).lo_prev_abs; stopped = 0; bail = 0; rolled = 1; \
         if (agatha_lanes16_probation) { prob = 1; prob_until = gave_up_at + 33; } else keys_only = 1; } while (0)
 run_again:
     for (;;) {
-        if (ck_span > 0 && !keys_only && i >= ck_span && i % ck_span == 0 && (prob || i < ewin)) SNAP_SAVE(snap[(i / ck_span) & 1]);
+        if (ck_span > 0 && !keys_only && i >= ck_span && i % ck_span == 0 && (prob || i < ewin)) SNAP_SAVE(snap[(i / ck_span) % nslots]);
         const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
         int n_in_flight = 0;        /* a block of this step works on a query word that holds an N (or the padding behind the query's end) */
         for (int k = 0; k < G; k++)
@@ -569,7 +580,7 @@ run_again:
                 const int64_t nb = ub > best ? ub : best, lo_both = lo_abs < lo_prev_abs ? lo_abs : lo_prev_abs;
                 calm = !final && (8 * i + 7 < lim) && LO != INT_MIN && lo_prev_abs != INT_MIN && LO >= L16_LO + spread + L16_DELTA + 7 * ge &&
                        lo_abs >= NEG_INF2 + spread && (z < 0 || nb - lo_both <= z);
-                if (!calm) { int pk; SNAP_PICK(pk); if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) & 1) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); continue; } again = 1; break; }
+                if (!calm) { int pk; SNAP_PICK(pk); if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) % nslots) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); continue; } again = 1; break; }
                 if (ub > best) { best = (int)ub; pos_known = 0; }
                 lo_prev_abs = lo_abs;
             } else {
@@ -600,7 +611,7 @@ run_again:
                     if (!comfy) prob_until = imax(prob_until, i + 33);
                     else if (i + 1 >= prob_until) { prob = 0; ewin = ewin0; __sync_fetch_and_add(&agatha_lanes16_left_probation, 1); }
                 }
-                if (!calm && (stale || !pos_known)) { int pk; SNAP_PICK(pk); if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) & 1) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); continue; } again = 1; break; }
+                if (!calm && (stale || !pos_known)) { int pk; SNAP_PICK(pk); if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) % nslots) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); continue; } again = 1; break; }
             }
             prev_fast = fast;
         }
@@ -675,14 +686,14 @@ run_again:
 #undef REB
     if (margin > 0 && !bail && !pos_known && !again) {          /* the pair ends without the cell of its maximum */
         int pk; SNAP_PICK(pk);
-        if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) & 1) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); goto run_again; }
+        if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) % nslots) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); goto run_again; }
         again = 1;
     }
     __sync_fetch_and_add(&agatha_lanes16_steps[0], n_value); __sync_fetch_and_add(&agatha_lanes16_steps[1], n_key);
     l16_tl_steps[0] += n_value; l16_tl_steps[1] += n_key;
     out3[0] = best; out3[1] = best_q; out3[2] = best_t;
     if (stats) { stats[0] = vmin; stats[1] = vmax; stats[2] = bail ? INT_MIN : gmax; stats[3] = bail ? INT_MAX : rmin; }
-    free(pq); free(L); free(snap[0].L); free(snap[1].L);
+    free(pq); free(L); for (int sl = 0; sl < L16_MAX_SLOTS; sl++) free(snap[sl].L);
 #undef SNAP_SAVE
 #undef SNAP_PICK
 #undef SNAP_LOAD

@@ -94,6 +94,7 @@ def bursts(a):
     import ctypes as C
     lib = O.lib()
     span, prob, left = (C.c_int.in_dll(lib, n) for n in ("agatha_lanes16_ck_span", "agatha_lanes16_probation", "agatha_lanes16_left_probation"))
+    C.c_int.in_dll(lib, "agatha_lanes16_ck_slots").value = a.slots
     steps = (C.c_longlong * 2).in_dll(lib, "agatha_lanes16_steps")
     per_pair = C.c_void_p.in_dll(lib, "agatha_lanes16_pair_steps")
     lines = []
@@ -102,7 +103,7 @@ def bursts(a):
         print(s, flush=True)
         lines.append(s)
 
-    emit(f"# tools/cliff_sweep.py --bursts margin={a.margin}: a burst of errors (sub 15 % ins 12 % del 13 %) in EVERY read of a cell, checkpoints as the kernel takes them (every 256 steps),")
+    emit(f"# tools/cliff_sweep.py --bursts margin={a.margin}: a burst of errors (sub 15 % ins 12 % del 13 %) in EVERY read of a cell, a checkpoint every {a.span} steps in {a.slots} slots (the kernel: 256, 2),")
     emit("# probation off / on (DESIGN.md 3.6).  back% = pairs that went back to a checkpoint, ret% = returns to value steps per pair that went back,")
     emit("# over% = pairs that (also) started from their first step, cost = (value steps + 1.4 key steps) / the same cell without a burst; every result checked against the oracle")
     emit("# tail% = what ONE such pair costs the wave that holds it on the static schedule, where the kernel ends with its last wave: the steps the pair runs beyond")
@@ -133,7 +134,7 @@ def bursts(a):
             exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=a.threads)
             cells = []
             for on in (0, 1):
-                span.value, prob.value = 256, on
+                span.value, prob.value = a.span, on
                 left.value = 0; steps[0] = steps[1] = 0
                 pp = np.zeros((n, 2), np.int64)
                 per_pair.value = pp.ctypes.data
@@ -166,6 +167,8 @@ def main():
     ap.add_argument("--threads", type=int, default=max(1, len(os.sched_getaffinity(0))))
     ap.add_argument("--shapes", default="C0,C1,C2")
     ap.add_argument("--old-window", action="store_true", help="round 4's rule for the window of key steps (3/2 (slack + 7 ge) i / best, no prior, no cap): the 'before' of round 5")
+    ap.add_argument("--span", type=int, default=256, help="--bursts: steps between two checkpoints (the kernel: 256 for pairs of 2 048 .. 4 095 steps, debug option ck_shift 28; 27 = 128, 26 = 64)")
+    ap.add_argument("--slots", type=int, default=2, help="--bursts: a what-if -- a ring of that many checkpoints instead of the kernel's two (agatha_lanes16_ck_slots)")
     ap.add_argument("--bursts", action="store_true", help="the other table (round 5): reads with a burst of errors (a dip of the score that recovers), with the kernel's checkpoints, probation off and on: who goes back, who returns to value steps, what the batch costs in steps")
     a = ap.parse_args()
     if a.bursts:
