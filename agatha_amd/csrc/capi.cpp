@@ -45,7 +45,7 @@ DebugOption g_opts[] = {
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
     {"force_split", "AGATHA_AMD_FORCE_SPLIT", {0}},    // > 0: this many pairs (the longest) on the latency shape beside the throughput shape, whatever the cost model says (tests)
     {"ck_newer", "AGATHA_AMD_CK_NEWER", {1}},          // int16 kernel: 1 = a pair that must go back takes the newer of its two checkpoints when the bound of its maximum has risen far enough behind it (three register pairs per lane) / the checkpoint before "keep" when it has hardly risen behind "keep" (one or two), 0 = always the older one / always "keep" (round 3)
-    {"ck_shift", "AGATHA_AMD_CK_SHIFT", {28}},         // int16 kernel: a pair of s steps takes a checkpoint every 2^(n - clz(s)) steps (28: every eighth to sixteenth of the pair, 29: quarter to eighth)
+    {"ck_shift", "AGATHA_AMD_CK_SHIFT", {agatha::kCkSlots16 > 2 ? 26 : 28}},         // int16 kernel: a pair of s steps takes a checkpoint every 2^(n - clz(s)) steps (28: every eighth to sixteenth of the pair, 29: quarter to eighth)
     {"lat_blocks", "AGATHA_AMD_LAT_BLOCKS", {0}},      // > 0: a batch split by length keeps its long pairs on this many workgroups of the latency shape (experiments; 0: no cap)
     {"no_split", "AGATHA_AMD_NO_SPLIT", {0}},          // 1: a batch of mixed lengths is never split between the two int16 shapes (one shape per launch, as before round 4)
     {"prio_fine", "AGATHA_AMD_PRIO_FINE", {0}},        // quarters of a slice added to slot 0's share of the issue priority (static schedule)
@@ -162,7 +162,7 @@ size_t ck_part_bytes(uint32_t n, bool lat)
 {
     size_t need = 0;
     for (const CkShape& s : kCkShapes)
-        if ((s.G >= 64) == lat) need = std::max(need, ck_groups(s.G, n) * 2 * (size_t)agatha::align16_mig_fields(s.P) * (size_t)s.G * sizeof(uint32_t));
+        if ((s.G >= 64) == lat) need = std::max(need, ck_groups(s.G, n) * (size_t)agatha::kCkSlots16 * (size_t)agatha::align16_mig_fields(s.P) * (size_t)s.G * sizeof(uint32_t));
     return round_up(need);
 }
 size_t ck_workspace_bytes(uint32_t n) { return ck_part_bytes(n, false) + ck_part_bytes(n, true); }

@@ -105,6 +105,15 @@ constexpr int kAlign16MaxMatch = 16, kAlign16MaxMismatch = 32, kAlign16MaxGapOpe
 // score profiles: ~4 dependent memory round trips), in steps, per lane group of the wave -- every start stalls all the
 // groups of its wave, so a pair costs its group kMigPairOverheadSteps * (64 / G) steps; the schedule counts that, so that
 // lane groups holding many tiny pairs are not the last to finish
+// EXPERIMENTAL, not the product build (compile with -DAGATHA16_CK_RING=4): the three-register-pair shapes of the int16 kernel
+// keep a RING of that many checkpoints per lane group instead of two, 64 steps apart where the product's two are 256 apart -- the same reach, a
+// quarter of the grain: a pair that gives up goes back to the newest one that lies before the last rise of its maximum.  Tried in the CPU model
+// only (oracle/agatha_lanes_model.c agatha_lanes16_ck_slots, tools/cliff_sweep.py --bursts --span 64 --slots 4); it compiles; it has never run.
+#ifndef AGATHA16_CK_RING
+#define AGATHA16_CK_RING 2
+#endif
+constexpr int kCkSlots16 = AGATHA16_CK_RING;            // checkpoint slots per lane group in the checkpoint area (every shape's stride)
+static_assert(kCkSlots16 == 2 || kCkSlots16 == 4 || kCkSlots16 == 8, "two slots (the product), or a ring of four or eight");
 constexpr int kMigPairOverheadSteps = 4;
 constexpr int kMigMaxSlots = 16384;
 constexpr int kSimdStepsInts = 2 * 4 * 1024;          // (up to 1024 CUs)
