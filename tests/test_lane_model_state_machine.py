@@ -119,7 +119,7 @@ def test_probation_returns_a_pair_to_value_steps_and_changes_no_result(knobs):
         went_back, returned, _, key_on = seen[1]
         assert seen[0][0] >= 24 and went_back >= 24, seen             # half the pairs and more go back to a checkpoint
         assert seen[0][1] == 0 and returned >= went_back // 2, seen   # ... and most of those leave their probation
-        assert key_on < 0.6 * seen[0][3], seen                        # the batch's key steps (62 k -> 27 k when this was written)
+        assert key_on < 0.6 * seen[0][3], seen                        # the batch's key steps (44 k -> 20 k when this was written)
         # broken reads (z-drop ends a third of them): pairs that give up on probation start from their first step; every span, exact
         (qb, qo, ql), (tb, to, tl) = _batch(11, 220)
         p = O.make_params(m=1, x=4, q=6, r=2, z=400)
