@@ -45,7 +45,7 @@ DebugOption g_opts[] = {
     {"timeline", "AGATHA_AMD_TIMELINE", {0}},          // 1: every wave of the int16 kernel records when and where it ran
     {"force_split", "AGATHA_AMD_FORCE_SPLIT", {0}},    // > 0: this many pairs (the longest) on the latency shape beside the throughput shape, whatever the cost model says (tests)
     {"ck_newer", "AGATHA_AMD_CK_NEWER", {1}},          // int16 kernel: 1 = a pair that must go back takes the newer of its two checkpoints when the bound of its maximum has risen far enough behind it (three register pairs per lane) / the checkpoint before "keep" when it has hardly risen behind "keep" (one or two), 0 = always the older one / always "keep" (round 3)
-    {"ck_shift", "AGATHA_AMD_CK_SHIFT", {agatha::kCkSlots16 > 2 ? 26 : 28}},         // int16 kernel: a pair of s steps takes a checkpoint every 2^(n - clz(s)) steps (28: every eighth to sixteenth of the pair, 29: quarter to eighth)
+    {"ck_shift", "AGATHA_AMD_CK_SHIFT", {28}},         // int16 kernel: a pair of s steps takes a checkpoint every 2^(n - clz(s)) steps (28: every eighth to sixteenth of the pair, 29: quarter to eighth)
     {"lat_blocks", "AGATHA_AMD_LAT_BLOCKS", {0}},      // > 0: a batch split by length keeps its long pairs on this many workgroups of the latency shape (experiments; 0: no cap)
     {"no_split", "AGATHA_AMD_NO_SPLIT", {0}},          // 1: a batch of mixed lengths is never split between the two int16 shapes (one shape per launch, as before round 4)
     {"prio_fine", "AGATHA_AMD_PRIO_FINE", {0}},        // quarters of a slice added to slot 0's share of the issue priority (static schedule)
@@ -61,8 +61,9 @@ DebugOption g_opts[] = {
     {"no_pool", "AGATHA_AMD_NO_POOL", {0}},             // static schedule: 1 = every lane group resumes the pair that crosses out of its own interval (until round 4); 0 = the rests of the suspended pairs are a pool, longest first, for whoever is done with its fixed part
     {"mig_identity", "AGATHA_AMD_MIG_IDENTITY", {0}},   // static schedule: 1 = lane group g owns interval g of the line of pairs (until round 4); 0 = intervals whose pairs end together share a wave (schedule_kernel)
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {384}},    // int16 kernel: pairs of at least this many steps take checkpoints (0: none do; 1024 until late in round 4: 3 kb pairs with broken reads among them, 22 -> 19 ms)
+    {"poison_state", "AGATHA_AMD_POISON_STATE", {0}},     // tests: n > 0 = the int16 kernel writes the n-th suspended pair of a launch with a garbage step counter; 1000 + n = the same behind a flag that lets it pass the resume check, for the bound inside the step loop (see AlignLaunch::poison_state, agatha_amd_guard_stats)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_FLAT_DETECT, OPT_FLAT_PERCENT, OPT_CLEANUP_MIN_STEPS, OPT_PROBATION, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_FLAT_DETECT, OPT_FLAT_PERCENT, OPT_CLEANUP_MIN_STEPS, OPT_PROBATION, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_POISON_STATE, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -74,6 +75,7 @@ int opt(int which) { init_opts(); return g_opts[which].value.load(std::memory_or
 
 constexpr uint32_t kBuckets = 16384;     // sort buckets of 32 bases of (query + target) length
 constexpr size_t kAlign = 256;
+constexpr size_t kQueueBytes = 2 * kAlign;       // the queue block: 64 counters of round 1-5 (queue heads, totals, choice, kinds, step statistics) + the guard counters of round 6
 size_t round_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 int num_cus()
@@ -137,7 +139,7 @@ void aux_stream_drop(void* main_stream)
 constexpr uint32_t kMigMinPairs = 4096;
 size_t base_workspace_bytes(uint32_t n)
 {
-    return round_up(sizeof(uint32_t) * (size_t)n) + round_up(sizeof(uint32_t) * kBuckets) + kAlign +
+    return round_up(sizeof(uint32_t) * (size_t)n) + round_up(sizeof(uint32_t) * kBuckets) + kQueueBytes +
            round_up(sizeof(agatha::AlignLaunch)) + round_up((size_t)n) + round_up(sizeof(int) * agatha::kSimdStepsInts);
 }
 size_t mig_workspace_bytes(uint32_t n)
@@ -384,7 +386,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     char* ws = (char*)d_workspace;
     uint32_t* order = (uint32_t*)ws;             ws += round_up(sizeof(uint32_t) * (size_t)n_alns);
     uint32_t* hist = (uint32_t*)ws;              ws += round_up(sizeof(uint32_t) * kBuckets);
-    unsigned int* queue = (unsigned int*)ws;     ws += kAlign;
+    unsigned int* queue = (unsigned int*)ws;     ws += kQueueBytes;
     agatha::AlignLaunch* rec = (agatha::AlignLaunch*)ws;   ws += round_up(sizeof(agatha::AlignLaunch));
     uint8_t* exotic = (uint8_t*)ws;                          ws += round_up((size_t)n_alns);
     int* simd_steps = (int*)ws;                              ws += round_up(sizeof(int) * agatha::kSimdStepsInts);
@@ -405,7 +407,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     // [16..18] the schedule, [20..23] step statistics of the int16 kernel
     float* totals = (float*)(queue + 8);
     int* choice = (int*)(queue + 10);
-    HIPCHK(hipMemsetAsync(queue, 0, kAlign, st));
+    HIPCHK(hipMemsetAsync(queue, 0, kQueueBytes, st));
     HIPCHK(agatha::launch_sort(d_query_lens, d_target_lens, (int)n_alns, hist, kBuckets, order, totals, st));
 
     agatha::AlignLaunch L;
@@ -418,6 +420,8 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.exotic = exotic;
     L.kind_counts = queue + 12;
     L.step_stats = queue + 20;
+    L.guard_stats = queue + 64;
+    L.poison_state = opt(OPT_POISON_STATE);
     L.score_limit = score_limit;
     L.force_cmp = (tb || sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     L.tb_codes = nullptr; L.tb_off = nullptr; L.tb_pass = nullptr; L.tb_plan = nullptr; L.tb_lanes = 0;
@@ -656,7 +660,7 @@ int agatha_amd_kernel_choice(void* stream, const void* d_workspace, uint32_t n_a
     int choice = 0;
     agatha::AlignLaunch rec;
     hipError_t e = hipMemcpyAsync(&choice, ws + 10 * sizeof(unsigned int), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&rec, ws + kAlign, sizeof(rec), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&rec, ws + kQueueBytes, sizeof(rec), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "agatha_amd_kernel_choice");
     if (choice < 0 || choice >= rec.ncand) return AGATHA_AMD_EINVAL;
@@ -672,7 +676,7 @@ int agatha_amd_split_info(void* stream, const void* d_workspace, uint32_t n_alns
     unsigned int n_long = 0;
     agatha::AlignLaunch rec;
     hipError_t e = hipMemcpyAsync(&n_long, ws + 11 * sizeof(unsigned int), sizeof(n_long), hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&rec, ws + kAlign, sizeof(rec), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&rec, ws + kQueueBytes, sizeof(rec), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "agatha_amd_split_info");
     out[0] = (int)n_long; out[1] = out[2] = 0;
@@ -699,6 +703,17 @@ int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns
     hipError_t e = hipMemcpyAsync(out, ws + 20 * sizeof(unsigned int), 40 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "agatha_amd_step_stats");
+    return 0;
+}
+
+int agatha_amd_guard_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[4], int synchronise)
+{
+    if (!d_workspace || !out || n_alns == 0) return AGATHA_AMD_EINVAL;
+    const char* ws = (const char*)d_workspace;
+    ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets);
+    hipError_t e = hipMemcpyAsync(out, ws + 64 * sizeof(unsigned int), 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess && synchronise) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "agatha_amd_guard_stats");
     return 0;
 }
 
@@ -732,7 +747,7 @@ int agatha_amd_pair_kinds(void* stream, const void* d_workspace, uint32_t n_alns
 {
     if (!d_workspace || !counts || n_alns == 0) return AGATHA_AMD_EINVAL;
     const char* ws = (const char*)d_workspace;
-    ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets) + kAlign + round_up(sizeof(agatha::AlignLaunch));
+    ws += round_up(sizeof(uint32_t) * (size_t)n_alns) + round_up(sizeof(uint32_t) * kBuckets) + kQueueBytes + round_up(sizeof(agatha::AlignLaunch));
     uint8_t* h = (uint8_t*)malloc(n_alns);
     if (!h) return AGATHA_AMD_EINVAL;
     hipError_t e = hipMemcpyAsync(h, ws, n_alns, hipMemcpyDeviceToHost, (hipStream_t)stream);

@@ -64,6 +64,13 @@ struct AlignLaunch {
     int prio_duty;                 // of every 16 slices, the wave in slot 0 of its SIMD is the favoured one in this many
     int prio_fine;                 // ... plus this many quarters of a slice (debug option prio_fine: the arbiter is not quite even-handed)
     unsigned int mig_test_delay_ticks;   // tests: odd lane groups sleep this long before they start (forces the take-over)
+    // packed-int16 kernel, the hard bounds of round 6 (align16_step_maxima.inc, align16_acquire.inc): [0] pairs handed to the int32 kernel because their
+    // step counter had run past the pair's last step, [1] ... because the state they were to be resumed from (a suspended pair, a checkpoint, a
+    // fallback) failed its check (this pair, this launch, 0 <= step <= steps of the pair, the slice counter in range), [2] saved states poisoned
+    // by the debug option poison_state (tests).  Non-zero [0] / [1] means memory the kernel owns was corrupted or its state machine has a bug:
+    // the results are still right (the int32 kernel redoes those pairs), and the host says so loudly.
+    unsigned int* guard_stats;
+    int poison_state;              // tests (debug option poison_state): n > 0 = the n-th suspended state of the launch is written with a garbage step counter (n + 1000: behind a flag that lets it pass the resume check, so that only the bound inside the step loop can end the pair)
     unsigned int* step_stats;      // device: [0] value wave-steps, [1] key wave-steps, [2] pairs started over, [3] pairs started (int16 kernel)
     uint32_t* ck_buf;              // device: checkpoints of the int16 kernel's long pairs, two slots of a suspended pair's size per lane group (nullptr: none)
     unsigned long long ck_dwords;  // dwords of that area ...
@@ -105,15 +112,10 @@ constexpr int kAlign16MaxMatch = 16, kAlign16MaxMismatch = 32, kAlign16MaxGapOpe
 // score profiles: ~4 dependent memory round trips), in steps, per lane group of the wave -- every start stalls all the
 // groups of its wave, so a pair costs its group kMigPairOverheadSteps * (64 / G) steps; the schedule counts that, so that
 // lane groups holding many tiny pairs are not the last to finish
-// EXPERIMENTAL, not the product build (compile with -DAGATHA16_CK_RING=4): the three-register-pair shapes of the int16 kernel
-// keep a RING of that many checkpoints per lane group instead of two, 64 steps apart where the product's two are 256 apart -- the same reach, a
-// quarter of the grain: a pair that gives up goes back to the newest one that lies before the last rise of its maximum.  Tried in the CPU model
-// only (oracle/agatha_lanes_model.c agatha_lanes16_ck_slots, tools/cliff_sweep.py --bursts --span 64 --slots 4); it compiles; it has never run.
-#ifndef AGATHA16_CK_RING
-#define AGATHA16_CK_RING 2
-#endif
-constexpr int kCkSlots16 = AGATHA16_CK_RING;            // checkpoint slots per lane group in the checkpoint area (every shape's stride)
-static_assert(kCkSlots16 == 2 || kCkSlots16 == 4 || kCkSlots16 == 8, "two slots (the product), or a ring of four or eight");
+// checkpoint slots per lane group in the checkpoint area (every shape's stride).  (Round 6: a RING of eight slots 64 steps apart, the CPU
+// model's favourite of round 5, was run on the chip -- profiles/r06_v0/ring8_*: reads with a 350-base burst 35.2 against 33.5 ms, the clean
+// batch + 1 %, the flat-batch test fails (6 364 pairs go back to a checkpoint) -- and taken out again; two slots it is.)
+constexpr int kCkSlots16 = 2;
 constexpr int kMigPairOverheadSteps = 4;
 constexpr int kMigMaxSlots = 16384;
 constexpr int kSimdStepsInts = 2 * 4 * 1024;          // (up to 1024 CUs)

@@ -101,6 +101,8 @@ def load_library():
     lib.agatha_amd_step_stats.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint)]
     if hasattr(lib, "agatha_amd_flat_stats"):        # (developer A/B runs load older builds through AGATHA_AMD_LIB)
         lib.agatha_amd_flat_stats.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint)]
+    if hasattr(lib, "agatha_amd_guard_stats"):
+        lib.agatha_amd_guard_stats.argtypes = [vp, vp, C.c_uint32, vp, C.c_int]
     lib.agatha_amd_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.agatha_amd_free.argtypes = [vp]
     lib.agatha_amd_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -124,7 +126,7 @@ EXPORTS = [
     "agatha_amd_set_device", "agatha_amd_max_band", "agatha_amd_workspace_bytes", "agatha_amd_workspace_bytes_long", "agatha_amd_pack", "agatha_amd_pack_host",
     "agatha_amd_seq_ops", "agatha_amd_align", "agatha_amd_starts_scratch_bytes", "agatha_amd_align_starts", "agatha_amd_traceback_pair_bytes",
     "agatha_amd_traceback_scratch_bytes",
-    "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_split_info", "agatha_amd_pack2_host", "agatha_amd_unpack2", "agatha_amd_step_stats", "agatha_amd_flat_stats", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
+    "agatha_amd_align_traceback", "agatha_amd_set_debug_option", "agatha_amd_get_debug_option", "agatha_amd_set_kernel_events", "agatha_amd_last_config", "agatha_amd_last_int16_config", "agatha_amd_pair_kinds", "agatha_amd_kernel_choice", "agatha_amd_schedule_info", "agatha_amd_split_info", "agatha_amd_pack2_host", "agatha_amd_unpack2", "agatha_amd_step_stats", "agatha_amd_flat_stats", "agatha_amd_guard_stats", "agatha_amd_timeline", "agatha_amd_malloc", "agatha_amd_free",
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
@@ -232,8 +234,13 @@ class DeviceBatch:
         # results land in pinned host memory (as the reference's cudaHostAlloc'd host_res, ctors.cpp): the D2H copy is
         # then really asynchronous and the host can enqueue the next batch while this one runs
         hp = C.c_void_p()
-        _chk(lib, lib.agatha_amd_host_alloc(C.byref(hp), 12 * self.n))
+        _chk(lib, lib.agatha_amd_host_alloc(C.byref(hp), 12 * self.n + 16))
         self._res_pinned = hp.value
+        # (behind the results: the four guard counters of the int16 kernel, agatha_amd_guard_stats -- copied with every download, looked at
+        #  when the stream is next waited for)
+        self._guard = np.ctypeslib.as_array((C.c_uint32 * 4).from_address(hp.value + 12 * self.n))
+        self._guard[:] = 0
+        self._guard_pending = False
         self.res_host = np.ctypeslib.as_array((C.c_int32 * (3 * self.n)).from_address(hp.value)).reshape(3, self.n)
         self.res_host[:] = 0
 
@@ -445,6 +452,32 @@ class DeviceBatch:
         st = stream if stream is not None else self.eng.stream
         for k in range(3):
             _chk(lib, lib.agatha_amd_memcpy_d2h_async(st, self.res_host[k].ctypes.data, self.d_res[k].ptr, 4 * self.n))
+        if hasattr(lib, "agatha_amd_guard_stats") and getattr(self, "_guard", None) is not None:
+            _chk(lib, lib.agatha_amd_guard_stats(st, self.d_ws.ptr, self.n, self._guard.ctypes.data, 0))
+            if st == self.eng.stream:       # (another stream: Engine.synchronize() does not wait for it -- ask guard_stats())
+                self._guard_pending = True
+                self.eng._guarded.add(self)
+
+    def guard_stats(self, stream=None):
+        """(pairs that left for the int32 kernel because their step counter had run past their last step, ... because the state they were
+        to be resumed from failed its check, states poisoned by the debug option poison_state, suspended states counted while it is on) of
+        the int16 kernel in the last align(): agatha_amd_guard_stats.  Waits for the stream."""
+        lib = self.eng.lib
+        st = stream if stream is not None else self.eng.stream
+        c = (C.c_uint * 4)()
+        _chk(lib, lib.agatha_amd_guard_stats(st, self.d_ws.ptr, self.n, C.addressof(c), 1))
+        return tuple(int(v) for v in c)
+
+    def _check_guard(self):
+        if self._guard_pending and self._guard is not None:
+            self._guard_pending = False
+            g = [int(v) for v in self._guard]
+            if g[0] or g[1]:
+                import warnings
+                warnings.warn(f"agatha_amd: the packed-int16 kernel ended {g[0]} pair(s) whose step counter had run past their last step and refused "
+                              f"{g[1]} saved state(s) that failed their check ({g[2]} poisoned on purpose by the debug option poison_state); those pairs "
+                              "were redone by the int32 kernel and the results are right, but device memory the kernel owns was overwritten or its "
+                              "state machine has a bug -- please report (agatha_amd_guard_stats)", RuntimeWarning, stacklevel=3)
 
     def packed_host(self):
         """Copies of the packed device buffers (for the pack-kernel parity test)."""
@@ -460,6 +493,8 @@ class DeviceBatch:
     def free(self):
         if getattr(self, "_res_pinned", None):
             self.res_host = None
+            self._guard = None
+            self.eng._guarded.discard(self)
             self.eng.lib.agatha_amd_host_free(self._res_pinned)
             self._res_pinned = None
         for b in [self.d_unp_q, self.d_unp_t, self.d_pk_q, self.d_pk_t, self.d_ws] + self.d_meta + self.d_res:
@@ -481,9 +516,13 @@ class Engine:
         s = C.c_void_p()
         _chk(self.lib, self.lib.agatha_amd_stream_create(C.byref(s)))
         self.stream = s.value
+        self._guarded = set()           # batches whose guard counters are on their way to the host (DeviceBatch.download)
 
     def synchronize(self):
         _chk(self.lib, self.lib.agatha_amd_stream_synchronize(self.stream))
+        for b in list(self._guarded):
+            b._check_guard()
+        self._guarded.clear()
 
     def last_config(self):
         g, s = C.c_int(0), C.c_int(0)

@@ -340,6 +340,8 @@ void gasal_init_streams(gasal_gpu_storage_v* vec, int max_query_len, int max_tar
         CHK(agatha_amd_stream_create(&s->str));
         CHK(agatha_amd_event_create(&s->ev_begin));
         CHK(agatha_amd_event_create(&s->ev_end));
+        s->guard_host = pin_alloc<unsigned int>(4);
+        memset(s->guard_host, 0, 4 * sizeof(unsigned int));
         s->is_free = 1;
         s->host_max_query_batch_bytes = s->gpu_max_query_batch_bytes = qbytes;
         s->host_max_target_batch_bytes = s->gpu_max_target_batch_bytes = tbytes;
@@ -367,6 +369,7 @@ void gasal_destroy_streams(gasal_gpu_storage_v* vec, Parameters* params)
         dev_free(s->starts_scratch); dev_free(s->tb_scratch);
         dev_free(s->unpacked_query_batch); dev_free(s->unpacked_target_batch);
         if (!params->isPacked) { dev_free(s->packed_query_batch); dev_free(s->packed_target_batch); }
+        pin_free(s->guard_host);
         if (s->ev_begin) CHK(agatha_amd_event_destroy(s->ev_begin));
         if (s->ev_end) CHK(agatha_amd_event_destroy(s->ev_end));
         if (s->str) CHK(agatha_amd_stream_destroy(s->str));
@@ -557,6 +560,10 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
     }
     CHK(rc);
     if (params->print_out) { CHK(agatha_amd_event_record(s->ev_end, s->str)); s->timing_pending = 1; s->timing_params = params; s->timing_n_alns = actual_n_alns; }
+    // the int16 kernel's guard counters of this batch, on their way to pinned memory behind the kernels (no wait; looked at in
+    // gasal_is_aln_async_done): pairs it ended or refused to resume because their saved state was not what it should be -- the int32 kernel
+    // has redone them, the results are right, and the user is told
+    if (s->guard_host) CHK(agatha_amd_guard_stats(s->str, s->workspace, actual_n_alns, s->guard_host, 0));
 
     if (params->start_pos) {
         // start positions (extension; the reference copies them back only if they are not NULL, gasal_align.cu:256-260, and they
@@ -628,6 +635,13 @@ int gasal_is_aln_async_done(gasal_gpu_storage_t* s)
         }
         s->timing_pending = 0;
         s->timing_params = nullptr;
+    }
+    if (s->guard_host && (s->guard_host[0] || s->guard_host[1])) {
+        fprintf(stderr, "[GASAL WARNING:] the packed-int16 kernel ended %u pair(s) whose step counter had run past their last step and refused %u saved "
+                        "state(s) that failed their check (%u poisoned on purpose: debug option poison_state); the int32 kernel redid those pairs and the "
+                        "results are right, but device memory of this library was overwritten or its state machine has a bug -- please report\n",
+                s->guard_host[0], s->guard_host[1], s->guard_host[2]);
+        memset(s->guard_host, 0, 4 * sizeof(unsigned int));
     }
     gasal_host_batch_reset(s);
     s->is_free = 1;

@@ -258,6 +258,15 @@ int agatha_amd_step_stats(void* stream, const void* d_workspace, uint32_t n_alns
  * option cleanup_min_steps), out[5] = positions of the sorted order that launch looked at.  Synchronises the stream. */
 int agatha_amd_flat_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[6]);
 
+/* The packed-int16 kernel's hard bounds (round 6): out[0] = pairs that left for the int32 kernel because their step counter had run past the
+ * pair's last step, out[1] = ... because the state they were to be resumed from (a suspended pair, a checkpoint, a fallback) failed its check,
+ * out[2] = states poisoned on purpose (debug option poison_state: tests), out[3] = suspended states counted while that option is on.  out[0] + out[1] > 0 without out[2] means that memory
+ * the kernel owns was overwritten or that its state machine has a bug; the results of the call are right all the same (the int32 kernel redid
+ * those pairs) and libgasal_amd / the Python binding print a warning.  Before round 6 such a state was a hung GPU (profiles/r05_v2/
+ * probation_hang_probe.txt).  synchronise != 0: waits for the stream; 0: only enqueues the copy (out must then be pinned host memory that stays
+ * valid until the stream has passed it: the Python binding reads it behind the results of every batch without a wait of its own). */
+int agatha_amd_guard_stats(void* stream, const void* d_workspace, uint32_t n_alns, unsigned int out[4], int synchronise);
+
 /* Diagnostics (debug option "timeline" = 1, workspace sized for > 4096 pairs): where and when every wave of the packed-int16
  * kernel ran in the last agatha_amd_align() on this workspace.  8 dwords per wave (wave = 4 * workgroup + wave in
  * workgroup): start and end in ticks of the 100 MHz real-time counter, HW_ID, XCC_ID, steps executed, pairs started, 2

@@ -128,6 +128,7 @@ typedef struct {
     size_t cigar_bytes;                 /* capacity of host_res->cigar / device_cpy->cigar */
     uint32_t cigar_alns;                /* capacity of host_res->n_cigar_ops / device_cpy->n_cigar_ops */
     void* timing_params;                /* Parameters* of the batch in flight: its raw_file gets the -p line */
+    unsigned int* guard_host;           /* pinned: the int16 kernel's four guard counters of the batch in flight (agatha_amd_guard_stats), looked at when the batch is done */
     int is_free;
     int id;
 } gasal_gpu_storage_t;

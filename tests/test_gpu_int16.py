@@ -437,6 +437,45 @@ def test_migration_take_over_when_the_first_part_never_comes(eng):
         agatha_amd.set_debug_option("force_choice", -1)
 
 
+@pytest.mark.parametrize("mode", [3, 1003])
+def test_a_poisoned_saved_state_ends_in_the_int32_kernel_not_in_a_hang(eng, mode):
+    """Round 6, the hard bounds of the int16 kernel.  In round 5 an unchecked saved state sent a wave to step 2 109 373 922 and the GPU suite
+    hung (profiles/r05_v2/probation_hang_probe.txt); the root cause was fixed, but nothing bounded a lane group's steps.  Now (a) every state a
+    pair is resumed from is checked -- this pair, this launch, a step inside the pair, a slice counter inside the slice -- and (b) a step counter
+    beyond the pair's last step ends the pair inside the step loop.  Either way the pair goes to the int32 kernel and is counted
+    (agatha_amd_guard_stats), the results are the oracle's, and the binding warns.  The debug option poison_state writes the third suspended
+    pair of the launch with a garbage step counter (mode 3: caught by (a)) or with one behind a flag that lets it pass (a) (mode 1003: caught by
+    (b), after a handful of steps)."""
+    qs, ts = _mig_batch(9000, 41, 200, 900)
+    p = dict(BASE, w=24)
+    agatha_amd.set_debug_option("force_choice", 0)
+    qb, qo, ql = WL.make_batch(qs)
+    tb, to, tl = WL.make_batch(ts)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=8)
+    b = eng.batch(qb, tb, qo, to, ql, tl)
+    try:
+        b.upload(); b.pack()
+        with agatha_amd.debug_options(poison_state=mode):
+            b.align(agatha_amd.Scores.make(**p)); b.download()
+            with pytest.warns(RuntimeWarning, match="packed-int16 kernel"):
+                eng.synchronize()
+            g = b.guard_stats()
+            kinds = b.pair_kinds()
+        assert b.schedule_info()[0]
+        got = [b.res_host[k].copy() for k in range(3)]
+        assert _same(got, exp)
+        assert g[2] == 1 and g[3] >= 3, g                      # one state poisoned
+        assert (g[0], g[1]) == ((0, 1) if mode < 1000 else (1, 0)), g
+        assert kinds[2] >= 1, kinds                            # ... and its pair redone by the int32 kernel
+        # the same batch without the option: no counter moves, no warning
+        b.align(agatha_amd.Scores.make(**p)); b.download(); eng.synchronize()
+        assert b.guard_stats() == (0, 0, 0, 0)
+        assert _same([b.res_host[k].copy() for k in range(3)], exp)
+    finally:
+        b.free()
+        agatha_amd.set_debug_option("force_choice", -1)
+
+
 def test_a_lane_group_that_never_started_is_taken_over_after_a_short_grace(eng):
     """Round 4: the only protection against a workgroup of the persistent grid that is not resident used
     to be a fixed 50 ms.  A boundary whose state is still FRESH when its left neighbour needs the pair says that the right
