@@ -74,6 +74,11 @@ PYEOF
 import json
 for l in open('$out/bench_configs.jsonl'):
     b=json.loads(l); print(b['config'].get('workload','?')[:40], 'kernel_ms', round(b.get('kernel_ms',0),2), 'value', round(b['value'],1))" ;;
+    tl)         # tl [pairs] [cfg]: the wave timeline of one batch on the tree's library and on every ab/*.so (kernel end = the last wave's end)
+        for lib in "" $(ls ab/*.so 2>/dev/null); do
+            echo "== lib=$(basename ${lib:-tree})" | tee -a $out/tl.txt
+            AGATHA_AMD_LIB=${lib:+$PWD/$lib} timeout 180 python3 tools/timeline_steps.py ${1:-10000} ${2:-cfg_c1} 2>&1 | head -4 | tee -a $out/tl.txt
+        done ;;
     lib)        # lib <name|tree>: the library (ab/<name>) every later recipe of the chain loads
         if [ "$1" = tree ]; then unset AGATHA_AMD_LIB; else export AGATHA_AMD_LIB=$PWD/ab/$1; fi ;;
     py)         # py <script> [args]: any tool of this directory
