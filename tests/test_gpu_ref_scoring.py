@@ -186,3 +186,43 @@ def test_a_read_with_a_burst_of_errors_returns_to_value_steps(eng):
     exp = O.align_batch(batch[0], batch[1], *sub, O.make_params(**REF), wide=True, model=O.MODEL_SLICES, threads=16)
     for on in (1, 0):
         assert all((g[pick] == e).all() for g, e in zip(runs[on][1], exp)), on
+
+
+@pytest.mark.parametrize("burst", [150, 350])
+def test_bundled_dataset_shape_with_bursts_of_errors_at_the_reference_scoring(eng, burst):
+    """Round 6: the same bursts in the 3 kb reads of the bundled-dataset shape (configs[0], the work queue: 2.4 rounds of pairs), where a read has
+    one checkpoint behind it or none -- dozens to hundreds of pairs start from their first step, and the ones that do so after the queue has run
+    dry are the kernel's tail (profiles/r06_v1/bursts.txt: + 25 ... + 33 % on the kernel).  Such a pair now leaves for the clean-up launch of the
+    latency shape (one pair per wave behind the kernel) instead of running 750 key steps alone.  Results: the oracle's, with the launch and
+    without it (debug option cleanup_min_steps = 0)."""
+    import agatha_amd
+    qs, ts0 = synth.cfg_c0(n=20000)
+    rng = np.random.default_rng(11)
+    ts, hit = [], []
+    for j, t in enumerate(ts0):
+        if rng.random() < 0.10 and len(t) * 4 // 5 - burst > len(t) // 5:
+            a = np.frombuffer(t, np.uint8).copy()
+            at = int(rng.integers(len(a) // 5, len(a) * 4 // 5 - burst))
+            t = np.concatenate([a[:at], synth.mutate(rng, a[at:at + burst], 0.15, 0.12, 0.13), a[at + burst:]]).tobytes()
+            hit.append(j)
+        ts.append(t)
+    runs = {}
+    try:
+        for cl in (384, 0):
+            agatha_amd.set_debug_option("cleanup_min_steps", cl)
+            runs[cl] = _run(eng, qs, ts, **REF)
+    finally:
+        agatha_amd.set_debug_option("cleanup_min_steps", 384)
+    batch, got, info = runs[384]
+    assert info["choice"][0] == "int16" and not info["sched"][0], info          # the work queue
+    st = info["st"]
+    assert st[2] + st[15] >= 20, st[:16]                                          # pairs do start over or go back: the case is the one meant
+    r = np.random.default_rng(9)
+    pick = np.sort(np.concatenate([r.choice(np.array(hit), min(600, len(hit)), replace=False),
+                                   r.choice(np.setdiff1d(np.arange(20000), np.array(hit)), 600, replace=False)]))
+    sub = [np.ascontiguousarray(a[pick]) for a in batch[2:]]
+    exp = O.align_batch(batch[0], batch[1], *sub, O.make_params(**REF), wide=True, model=O.MODEL_SLICES, threads=16)
+    for cl in (384, 0):
+        assert all((g[pick] == e).all() for g, e in zip(runs[cl][1], exp)), cl
+    assert all((a == b).all() for a, b in zip(runs[384][1], runs[0][1]))        # ... and all 20 000 agree between the two runs
+
