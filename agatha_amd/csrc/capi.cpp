@@ -780,6 +780,8 @@ int agatha_amd_stream_query(void* stream)
 int agatha_amd_event_create(void** event) { if (!event) return AGATHA_AMD_EINVAL; hipEvent_t e; HIPCHK(hipEventCreate(&e)); *event = (void*)e; return 0; }
 int agatha_amd_event_destroy(void* event) { if (event) HIPCHK(hipEventDestroy((hipEvent_t)event)); return 0; }
 int agatha_amd_event_record(void* event, void* stream) { HIPCHK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); return 0; }
+int agatha_amd_stream_wait_event(void* stream, void* event) { HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0)); return 0; }
+int agatha_amd_get_device(void) { int d = -1; HIPCHK(hipGetDevice(&d)); return d; }
 int agatha_amd_event_elapsed_ms(void* start, void* stop, float* ms)
 {
     if (!ms) return AGATHA_AMD_EINVAL;

@@ -130,7 +130,7 @@ EXPORTS = [
     "agatha_amd_host_alloc", "agatha_amd_host_free", "agatha_amd_memcpy_h2d_async",
     "agatha_amd_memcpy_d2h_async", "agatha_amd_stream_create", "agatha_amd_stream_destroy",
     "agatha_amd_stream_synchronize", "agatha_amd_stream_query", "agatha_amd_event_create",
-    "agatha_amd_event_destroy", "agatha_amd_event_record", "agatha_amd_event_elapsed_ms",
+    "agatha_amd_event_destroy", "agatha_amd_event_record", "agatha_amd_event_elapsed_ms", "agatha_amd_stream_wait_event", "agatha_amd_get_device",
 ]
 
 

@@ -415,6 +415,25 @@ void gasal_set_device(int gpu_select, bool isPrintingProp)
 }
 
 // ------------------------------------------------------------------------------------------------ the hot path
+// How many batches' align kernels may be on one GPU at once (round 6).  Every storage has its own stream, a client thread usually two storages
+// (the reference's NB_STREAMS, test_prog.cpp:12), and every align call is a persistent grid that fills the chip: two of them overlap usefully --
+// the tail of one under the head of the next, 1.06 x the single-batch rate in the steady state -- but with four client threads eight were
+// queued at once, whichever workgroups got on the chip belonged to five or six different grids and lane groups waited for partners that were
+// not resident.  So the align kernels of batch k of a device wait, on the device, for those of batch k - LIMIT (an event ring; the host never
+// blocks, H2D copies and the host's filling of other storages go on): more client threads then only add host-side overlap.
+// AGATHA_AMD_MAX_INFLIGHT: the limit (default 2, 0 = none).  Measured over 16-batch feeds (tools/pipe_sweep.py, profiles/r06_v1/pipe_sweep.txt):
+// two threads + 3-8 %, four threads + 1-3 %; four threads stay a few per cent behind two (the run-to-run spread of that figure is as large).
+namespace {
+constexpr int kGateRing = 64, kGateDevices = 64;
+struct DeviceGate { std::mutex mu; unsigned long long ticket = 0; void* done[kGateRing] = {nullptr}; };
+DeviceGate g_gate[kGateDevices];
+int gate_limit()
+{
+    static const int v = [] { const char* e = getenv("AGATHA_AMD_MAX_INFLIGHT"); const int x = (e && *e) ? atoi(e) : 2; return x < 0 ? 0 : (x > kGateRing / 2 ? kGateRing / 2 : x); }();
+    return v;
+}
+}  // namespace
+
 void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_bytes,
                      const uint32_t actual_target_batch_bytes, const uint32_t actual_n_alns, Parameters* params)
 {
@@ -542,6 +561,17 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
             s->tb_scratch_bytes = want;
         }
     }
+    // (the gate: from here to the event behind the align call one thread at a time per device, so that ring[k] is recorded before batch k + LIMIT asks for it)
+    const int gate_n = gate_limit();
+    const int gate_dev = gate_n > 0 ? agatha_amd_get_device() : -1;
+    DeviceGate* gate = (gate_dev >= 0 && gate_dev < kGateDevices) ? &g_gate[gate_dev] : nullptr;
+    std::unique_lock<std::mutex> gate_lock;
+    unsigned long long gate_k = 0;
+    if (gate) {
+        gate_lock = std::unique_lock<std::mutex>(gate->mu);
+        gate_k = gate->ticket++;
+        if (gate_k >= (unsigned long long)gate_n && gate->done[(gate_k - gate_n) % kGateRing]) CHK(agatha_amd_stream_wait_event(s->str, gate->done[(gate_k - gate_n) % kGateRing]));
+    }
     if (params->print_out) CHK(agatha_amd_event_record(s->ev_begin, s->str));
     int rc = params->traceback
         ? agatha_amd_align_traceback(s->str, s->packed_query_batch, s->packed_target_batch, s->query_batch_lens,
@@ -559,6 +589,12 @@ void gasal_aln_async(gasal_gpu_storage_t* s, const uint32_t actual_query_batch_b
         exit(EXIT_FAILURE);
     }
     CHK(rc);
+    if (gate) {
+        void*& ev = gate->done[gate_k % kGateRing];
+        if (!ev) CHK(agatha_amd_event_create(&ev));
+        CHK(agatha_amd_event_record(ev, s->str));
+        gate_lock.unlock();
+    }
     if (params->print_out) { CHK(agatha_amd_event_record(s->ev_end, s->str)); s->timing_pending = 1; s->timing_params = params; s->timing_n_alns = actual_n_alns; }
     // the int16 kernel's guard counters of this batch, on their way to pinned memory behind the kernels (no wait; looked at in
     // gasal_is_aln_async_done): pairs it ended or refused to resume because their saved state was not what it should be -- the int32 kernel

@@ -296,6 +296,11 @@ int agatha_amd_event_create(void** event);
 int agatha_amd_event_destroy(void* event);
 int agatha_amd_event_record(void* event, void* stream);
 int agatha_amd_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on stop */
+/* work enqueued on `stream` after this call waits for `event` (as last recorded); the host does not (hipStreamWaitEvent).  libgasal_amd's
+ * batch manager uses it to keep at most a few batches' align kernels on the chip at once however many host threads feed it. */
+int agatha_amd_stream_wait_event(void* stream, void* event);
+/* the device agatha_amd_set_device() selected for the calling thread (>= 0), or a negative error code */
+int agatha_amd_get_device(void);
 
 #ifdef __cplusplus
 }
