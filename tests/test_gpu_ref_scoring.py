@@ -226,3 +226,42 @@ def test_bundled_dataset_shape_with_bursts_of_errors_at_the_reference_scoring(en
         assert all((g[pick] == e).all() for g, e in zip(runs[cl][1], exp)), cl
     assert all((a == b).all() for a, b in zip(runs[384][1], runs[0][1]))        # ... and all 20 000 agree between the two runs
 
+
+def _dip_then_break(n=96, seed=23):
+    """30 kb reads with a 250-base burst of errors in the middle (the score dips by ~200 and recovers) and, 550 bases behind it, an unrelated
+    tail (z-drop ends the pair there): two give-ups less than a checkpoint span apart, the first one survivable."""
+    rng = np.random.default_rng(seed)
+    qs, ts = [], []
+    for _ in range(n):
+        L = int(rng.integers(28000, 32000))
+        ref = synth.random_seq(rng, L)
+        rd = synth.mutate(rng, ref, 0.03, 0.03, 0.04)
+        at = int(rng.integers(L * 2 // 5, L * 3 // 5))
+        a = rd.copy()
+        seg = synth.mutate(rng, a[at:at + 250], 0.15, 0.12, 0.13)
+        brk = at + 250 + int(rng.integers(500, 700))
+        rd2 = np.concatenate([a[:at], seg, a[at + 250:brk], synth.random_seq(rng, max(L - brk, 64))])
+        qs.append(ref.tobytes()); ts.append(rd2.tobytes())
+    return qs, ts
+
+
+def test_a_pair_that_went_back_once_finds_its_checkpoints_again(eng):
+    """Round 6 (profiles/r06_v2/c4_book_lost.txt): on the shapes that keep book of their checkpoints in a register (one or two register pairs
+    per lane: the latency shapes, HiFi bands) going back to a checkpoint emptied the book; a pair that then left its probation and gave up a
+    second time before the next checkpoint was due started from its FIRST step although both slots held a checkpoint of it -- the one
+    clean-then-broken 100 kb read of BASELINE configs[4] ran 42 000 steps, 109 instead of 63 ms for the batch.  Here: a dip, a recovery, a
+    break within one span; nobody starts from the first step far into the pair, and the results are the oracle's."""
+    import agatha_amd
+    qs, ts = _dip_then_break()
+    agatha_amd.set_debug_option("force_choice", 1)                 # the int16 latency shape: one pair per wave, book-keeping checkpoints
+    try:
+        batch, got, info = _run(eng, qs, ts, **REF)
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
+    assert info["choice"][0] == "int16" and info["choice"][1] >= 64, info
+    st = info["st"]
+    assert st[15] >= len(qs) // 2, st[:16]                         # the dips send pairs back to a checkpoint ...
+    assert st[2] == 0, st[:16]                                     # ... and the breaks behind them do not send anybody to the first step (round 5's library: 1 of these 96)
+    exp = O.align_batch(*batch, O.make_params(**REF), wide=True, model=O.MODEL_SLICES, threads=16)
+    assert all((g == e).all() for g, e in zip(got, exp))
+
