@@ -426,6 +426,7 @@ run_again:
         if (ck_span > 0 && !keys_only && i >= ck_span && i % ck_span == 0 && (prob || i < ewin)) SNAP_SAVE(snap[(i / ck_span) % nslots]);
         const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
         int n_in_flight = 0;        /* a block of this step works on a query word that holds an N (or the padding behind the query's end) */
+        const int one_cell = margin > 0 && (i + W + 6 < 2 * imin(pql, prl));      /* (the kernel's wave-uniform guard, here for the one pair) */
         for (int k = 0; k < G; k++)
             for (int x = 0; x < 7; x++) L[k].A[x] = ssub_sat(L[k].A[x], cb - cb_prev);
         for (int k = 0; k < G; k++) {
@@ -509,6 +510,9 @@ run_again:
                         if (x < nrows) v = imax(v, oh[x]);
                         lo = imin(lo, v);
                     }
+                    /* (round 6, boundary_bounds<true> of align16_block.inc: away from the pair's last rows and columns the lower bound comes from the
+                     *  block's two cells on its cell anti-diagonal 7 alone -- one gap below them lies a cell of each of the next seven anti-diagonals) */
+                    if (one_cell) { lo = INT_MIN; if (nrows == 8) lo = imax(lo, h[0]); if (0 < nrows) lo = imax(lo, oh[0]); }
                     ln->bhi[s] = hi; ln->blo[s] = lo;
                 }
                 for (int il = 0; il < 8; il++)
@@ -575,6 +579,7 @@ run_again:
                 int32_t LO = INT_MIN;
                 for (int k = 0; k < G; k++)
                     for (int sx = 0; sx < S; sx++) { LO = imax(LO, L[k].blo[sx]); HI = imax(HI, L[k].bhi[sx]); }
+                if (one_cell && LO != INT_MIN) LO -= gapo;          /* (one gap below the best cell of anti-diagonal 8i + 7, in the drifting frame) */
                 const int64_t lo_abs = LO == INT_MIN ? INT_MIN : (int64_t)LO + base - (int64_t)ge * (8 * i + 14);
                 const int64_t ub = HI == INT_MIN ? INT_MIN : (int64_t)HI + base - (int64_t)ge * (8 * i + 7) + slack;
                 const int64_t nb = ub > best ? ub : best, lo_both = lo_abs < lo_prev_abs ? lo_abs : lo_prev_abs;
