@@ -421,8 +421,8 @@ void gasal_set_device(int gpu_select, bool isPrintingProp)
 // queued at once, whichever workgroups got on the chip belonged to five or six different grids and lane groups waited for partners that were
 // not resident.  So the align kernels of batch k of a device wait, on the device, for those of batch k - LIMIT (an event ring; the host never
 // blocks, H2D copies and the host's filling of other storages go on): more client threads then only add host-side overlap.
-// AGATHA_AMD_MAX_INFLIGHT: the limit (default 2, 0 = none).  Measured over 16-batch feeds (tools/pipe_sweep.py, profiles/r06_v1/pipe_sweep.txt):
-// two threads + 3-8 %, four threads + 1-3 %; four threads stay a few per cent behind two (the run-to-run spread of that figure is as large).
+// AGATHA_AMD_MAX_INFLIGHT: the limit (default 2, 0 = none).  Measured over 16-batch feeds (tools/pipe_sweep.py, profiles/r06_v1/pipe_sweep.txt): within the
+// run-to-run spread (+- 5 %) of no limit for two threads; four threads stay behind two either way (what the kernel traces say about that).
 namespace {
 constexpr int kGateRing = 64, kGateDevices = 64;
 struct DeviceGate { std::mutex mu; unsigned long long ticket = 0; void* done[kGateRing] = {nullptr}; };

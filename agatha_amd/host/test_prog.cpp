@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <chrono>
+#include <thread>
 
 #include <vector>
 
@@ -120,9 +121,12 @@ int main(int argc, char** argv)
         for (int z = 0; z < NB_STREAMS; z++) { slot[z].st = &vecs[tid].a[z]; slot[z].n = 0; }
 
         while (batches_done < n_batches) {
+            bool progress = false;      // (round 6) an iteration that neither launched nor finished a batch backs off: four threads spinning on the stream queries
+                                        // of eight storages fought the launching threads for the runtime's locks -- "-n 4" ran at the rate of "-n 1"
             int z = 0;
             while (z < NB_STREAMS && slot[z].st->is_free != 1) z++;
             if (seqs_done < n_seqs && z < NB_STREAMS) {
+                progress = true;
                 gasal_gpu_storage_t* st = slot[z].st;
                 uint32_t qidx = 0, tidx = 0;
                 int j = 0;
@@ -192,8 +196,10 @@ int main(int argc, char** argv)
                         }
                     }
                     batches_done++;
+                    progress = true;
                 }
             }
+            if (!progress) std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
         total_batches += batches_done;
     }
