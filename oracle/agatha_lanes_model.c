@@ -426,7 +426,7 @@ run_again:
         if (ck_span > 0 && !keys_only && i >= ck_span && i % ck_span == 0 && (prob || i < ewin)) SNAP_SAVE(snap[(i / ck_span) % nslots]);
         const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
         int n_in_flight = 0;        /* a block of this step works on a query word that holds an N (or the padding behind the query's end) */
-        const int one_cell = margin > 0 && (i + W + 6 < 2 * imin(pql, prl));      /* (the kernel's wave-uniform guard, here for the one pair) */
+        const int one_cell = margin > 0 && (z < 0 || 40 * gapo <= z) && (i + W + 6 < 2 * imin(pql, prl));      /* (the kernel's wave-uniform guard, here for the one pair; only where a gap open is small against z) */
         for (int k = 0; k < G; k++)
             for (int x = 0; x < 7; x++) L[k].A[x] = ssub_sat(L[k].A[x], cb - cb_prev);
         for (int k = 0; k < G; k++) {
