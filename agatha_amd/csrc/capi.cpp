@@ -474,7 +474,9 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
         // the window of key steps a pair starts with, before it has shown its own rate of rise (align16_body.inc, widen_window): the steps a
         // read with 15 % errors needs to rise by more than the slack of a value step's bound, 3.5 sigma
         const double m_ = sc->match, pen = std::max<double>(sc->match + sc->mismatch, 0.5 * sc->match + sc->gap_open + sc->gap_extend), e0 = 0.15;
-        const double X = 7.0 * std::max(sc->mismatch, 1) + 7.0 * sc->gap_extend, mu = 4.0 * (m_ - e0 * pen), V = 4.0 * e0 * pen * pen, k2 = 12.0;
+        // (+ 8 m where the upper bound comes from the blocks' last columns alone: align16_body.inc, `slack`)
+        const bool one_cell_ok = sc->z_threshold < 0 || 40 * sc->gap_open <= sc->z_threshold;
+        const double X = 7.0 * std::max(sc->mismatch, 1) + (one_cell_ok ? 8.0 * std::max(sc->match, 0) : 0.0) + 7.0 * sc->gap_extend, mu = 4.0 * (m_ - e0 * pen), V = 4.0 * e0 * pen * pen, k2 = 12.0;
         double n = 4096.0;
         if (mu > 0.0) { const double r = (std::sqrt(k2 * V) + std::sqrt(k2 * V + 4.0 * mu * X)) / (2.0 * mu); n = std::min(4096.0, r * r); }
         L.win_prior = (int)std::ceil(n);

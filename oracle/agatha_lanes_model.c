@@ -379,7 +379,10 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
         for (int x = 0; x < 15; x++) { L[k].A[x] = INT_MIN; L[k].AV[0][x] = INT_MIN; L[k].AV[1][x] = INT_MIN; }
         for (int x = 0; x < 7; x++) { L[k].CAR[0][x] = INT_MIN; L[k].CAR[1][x] = INT_MIN; }
     }
-    const int slack = 7 * imax(b, 1);
+    /* (round 6: + 8 match where the one-cell / last-column bounds of boundary_bounds<true> may be used -- the upper bound then comes from the blocks'
+     *  LAST COLUMNS alone, and a cell that leaves its block downwards is known only as "at most eight diagonal moves above a cell of an earlier step") */
+    const int one_cell_ok = margin > 0 && (z < 0 || 40 * gapo <= z);
+    const int slack = 7 * imax(b, 1) + (one_cell_ok ? 8 * imax(a, 0) : 0);
     /* first step of the window of key steps: what a read with 15 % errors needs at this scoring (capi.cpp: win_prior), capped */
     const int win_anchor = 2 * (pql < prl ? pql : prl) - 1 - margin - ((pql + prl) >> 7);
     int ewin = win_anchor;
@@ -426,7 +429,7 @@ run_again:
         if (ck_span > 0 && !keys_only && i >= ck_span && i % ck_span == 0 && (prob || i < ewin)) SNAP_SAVE(snap[(i / ck_span) % nslots]);
         const int cb = 8 * imax(0, imax(i - pql + 1, (i - W + 1) >> 1) - 1);
         int n_in_flight = 0;        /* a block of this step works on a query word that holds an N (or the padding behind the query's end) */
-        const int one_cell = margin > 0 && (z < 0 || 40 * gapo <= z) && (i + W + 6 < 2 * imin(pql, prl));      /* (the kernel's wave-uniform guard, here for the one pair; only where a gap open is small against z) */
+        const int one_cell = one_cell_ok && (i + W + 6 < 2 * imin(pql, prl));      /* (the kernel's wave-uniform guard, here for the one pair; only where a gap open is small against z) */
         for (int k = 0; k < G; k++)
             for (int x = 0; x < 7; x++) L[k].A[x] = ssub_sat(L[k].A[x], cb - cb_prev);
         for (int k = 0; k < G; k++) {
@@ -512,7 +515,12 @@ run_again:
                     }
                     /* (round 6, boundary_bounds<true> of align16_block.inc: away from the pair's last rows and columns the lower bound comes from the
                      *  block's two cells on its cell anti-diagonal 7 alone -- one gap below them lies a cell of each of the next seven anti-diagonals) */
-                    if (one_cell) { lo = INT_MIN; if (nrows == 8) lo = imax(lo, h[0]); if (0 < nrows) lo = imax(lo, oh[0]); }
+                    if (one_cell) {
+                        lo = INT_MIN; if (nrows == 8) lo = imax(lo, h[0]); if (0 < nrows) lo = imax(lo, oh[0]);
+                        /* ... and the upper bound from the block's last column alone: every cell reaches the last column of its column block within
+                         * seven diagonal moves, in this row block or in the next one (which the next step measures) */
+                        hi = INT_MIN; for (int x = 0; x < 8; x++) hi = imax(hi, oh[x]);
+                    }
                     ln->bhi[s] = hi; ln->blo[s] = lo;
                 }
                 for (int il = 0; il < 8; il++)
