@@ -238,7 +238,8 @@ int agatha_amd_schedule_info(void* stream, const void* d_workspace, uint32_t n_a
  * pairs that were started over), out[2] = pairs started over on key steps (z-drop came into reach on a value step, or the
  * pair ended without knowing the cell of its maximum) from their first step, out[3] = pairs started, out[15] = pairs taken back to a
  * checkpoint instead, out[24] = pairs handed to the int32 kernel instead (static schedule without checkpoints: debug option
- * static_ck = 0); out[4..6] why (a value step that was not calm / a key step that needed the cell / the end of a pair without it);
+ * static_ck = 0); out[23] = (builds without -DAGATHA16_DIAG) the value steps among out[0] on which nothing was reduced or tested (round 6, "lazy" value steps of the shapes with one
+ * pair per wave: the last test answers for them; debug option lazy_max); out[4..6] why (a value step that was not calm / a key step that needed the cell / the end of a pair without it);
  * in builds with -DAGATHA16_DIAG only (tools/gpu_skew.py; zero otherwise): out[16..23] = how far back the checkpoint lay, in units of 256 steps; out[25..32] = how far the pairs that started from their first
  * step had come, in units of 512 steps, and out[33..37] why the ones beyond 1024 steps had no checkpoint to go back to (second time
  * / pair too short for checkpoints / before its second checkpoint / resumed pair: the state it was resumed from is used / slot

@@ -346,6 +346,8 @@ long long *agatha_lanes16_pair_steps = 0;
 static __thread long long l16_tl_steps[2];
 int agatha_lanes16_trace = 0;             /* tools: print every step's mode, bound and whether the cell of the maximum is known (stderr) */
 int agatha_lanes16_old_window = 0;        /* tools: round 4's rule for the window of key steps (3/2 (slack + 7 ge) i / best) */
+int agatha_lanes16_lazy_max = 8;          /* lazy value steps (round 6, one pair per wave: G >= 64): a passed test answers for at most this many steps behind it (0 = every step is tested) */
+int agatha_lanes16_lazy_any_shape = 0;    /* tests / tools: the rule on every shape (its arithmetic does not depend on the shape; the kernel uses it where a wave holds one pair) */
 
 int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_params_t *pr,
                          int G, int S, int32_t *out3, int32_t *stats)
@@ -394,6 +396,15 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
     }
     const int ewin0 = ewin;             /* (the window a pair starts with: first_window of align16_body.inc) */
     int64_t lo_prev_abs = INT_MIN;      /* value steps: lower bound (absolute score) of the maxima of this step's anti-diagonals 0..6 */
+    /* Lazy value steps (round 6, align16_body.inc: the shapes with one pair per wave, G >= 64): a test that passed with room to spare answers for
+     * the next steps as well.  From the cell the lower bound was read off, every later anti-diagonal holds a cell at most one gap lower (gap_open once,
+     * 8 ge per step), and the running maximum rises by at most 8 m per step; so after a test at step j with need = (bound of the running maximum) -
+     * (lower bound), the steps j + 1 .. j + k cannot z-drop while need + k (8 m + 8 ge) <= z.  On those steps the kernel computes no lower bound,
+     * reduces nothing and tests nothing: it keeps each lane's largest last-column cell (acc_ub here: its absolute bound) for the next test and lets
+     * the lower bound sink by 8 ge.  At most agatha_lanes16_lazy_max steps, never next to the window of key steps, a checkpoint or the pair's last
+     * rows and columns. */
+    int skip_until = 0;
+    int64_t acc_ub = INT_MIN;
     int best = 0, best_t = 0, best_q = 0, stopped = 0, bail = 0;
     int i = 0, y = 0, final = 0, cb_prev = 0;
     int ss = 0, se = imin(imin(prl - 1, sw - 1), ((sw - 1) * 8 + 7 + w) / 2 / 8);
@@ -420,7 +431,7 @@ int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_
         for (int kk_ = 0; kk_ < nslots; kk_++) { const int c_ = (i / ck_span) * ck_span - kk_ * ck_span; if (c_ < ck_span) break; if (c_ >= i) continue; \
             const snap_t *s_ = &snap[(c_ / ck_span) % nslots]; if (!s_->valid || s_->i != c_) continue; \
             (out) = (c_ / ck_span) % nslots; if (best - s_->best > slack + 14 * ge) break; } } } while (0)
-#define SNAP_LOAD(sn) do { const int gave_up_at = i; memcpy(L, (sn).L, sizeof(lane_t) * (size_t)G); i = (sn).i; y = (sn).y; final = (sn).final; cb_prev = (sn).cb_prev; ss = (sn).ss; se = (sn).se; \
+#define SNAP_LOAD(sn) do { const int gave_up_at = i; skip_until = 0; acc_ub = INT_MIN; memcpy(L, (sn).L, sizeof(lane_t) * (size_t)G); i = (sn).i; y = (sn).y; final = (sn).final; cb_prev = (sn).cb_prev; ss = (sn).ss; se = (sn).se; \
         base = (sn).base; best = (sn).best; best_t = (sn).best_t; best_q = (sn).best_q; pos_known = (sn).pos_known; prev_fast = (sn).prev_fast; ewin = (sn).ewin; \
         lo_prev_abs = (sn).lo_prev_abs; stopped = 0; bail = 0; rolled = 1; \
         if (agatha_lanes16_probation) { prob = 1; prob_until = gave_up_at + 33; } else keys_only = 1; } while (0)
@@ -567,6 +578,10 @@ run_again:
         /* (a wave runs key steps while a pair whose query holds an N has an N row in flight: align16_body.inc, want_keys) */
         const int fast = margin > 0 && i >= 1 && i < ewin && !n_in_flight && !keys_only && !prob;
         if (fast) n_value++; else n_key++;
+        /* (a key step behind lazy value steps: what they kept for the next test goes into the bound of the running maximum now) */
+        if (!fast && acc_ub != INT_MIN) { if (acc_ub > best) { best = (int)acc_ub; pos_known = 0; } acc_ub = INT_MIN; skip_until = 0; }
+        const int lazy = fast && prev_fast && one_cell && (G >= 64 || agatha_lanes16_lazy_any_shape) && agatha_lanes16_lazy_max > 0 && i + 1 < skip_until && i + 2 < ewin &&
+                         !(ck_span > 0 && (i + 1) % ck_span == 0);
         int calm = 0, stale = 0;
         int32_t HI = INT_MIN;
         if (margin > 0) {
@@ -589,13 +604,29 @@ run_again:
                     for (int sx = 0; sx < S; sx++) { LO = imax(LO, L[k].blo[sx]); HI = imax(HI, L[k].bhi[sx]); }
                 if (one_cell && LO != INT_MIN) LO -= gapo;          /* (one gap below the best cell of anti-diagonal 8i + 7, in the drifting frame) */
                 const int64_t lo_abs = LO == INT_MIN ? INT_MIN : (int64_t)LO + base - (int64_t)ge * (8 * i + 14);
-                const int64_t ub = HI == INT_MIN ? INT_MIN : (int64_t)HI + base - (int64_t)ge * (8 * i + 7) + slack;
+                int64_t ub = HI == INT_MIN ? INT_MIN : (int64_t)HI + base - (int64_t)ge * (8 * i + 7) + slack;
+                if (lazy) {
+                    /* nothing is tested: the last test answers for this step */
+                    if (ub > acc_ub) acc_ub = ub;
+                    if (lo_prev_abs != INT_MIN) lo_prev_abs -= 8 * (int64_t)ge;
+                    HI = INT_MIN;                                   /* (no rebase on such a step either) */
+                    prev_fast = fast;
+                    goto step_done;
+                }
+                if (acc_ub > ub) ub = acc_ub;
+                acc_ub = INT_MIN;
                 const int64_t nb = ub > best ? ub : best, lo_both = lo_abs < lo_prev_abs ? lo_abs : lo_prev_abs;
                 calm = !final && (8 * i + 7 < lim) && LO != INT_MIN && lo_prev_abs != INT_MIN && LO >= L16_LO + spread + L16_DELTA + 7 * ge &&
                        lo_abs >= NEG_INF2 + spread && (z < 0 || nb - lo_both <= z);
                 if (!calm) { int pk; SNAP_PICK(pk); if (pk >= 0) { __sync_fetch_and_add(&agatha_lanes16_ck_counts[pk == ((i / ck_span) % nslots) ? 0 : 1], 1); SNAP_LOAD(snap[pk]); continue; } again = 1; break; }
                 if (ub > best) { best = (int)ub; pos_known = 0; }
                 lo_prev_abs = lo_abs;
+                {   /* how many steps this test answers for */
+                    const int64_t d_ = 8 * (int64_t)imax(a, 0) + 8 * (int64_t)ge, need_ = (int64_t)best - lo_both;
+                    int64_t k_ = z < 0 ? agatha_lanes16_lazy_max : (d_ > 0 ? ((int64_t)z - need_) / d_ : 0);
+                    if (k_ > agatha_lanes16_lazy_max) k_ = agatha_lanes16_lazy_max;
+                    skip_until = i + 1 + (int)(k_ > 0 ? k_ : 0);
+                }
             } else {
                 int32_t lo8 = INT_MIN, mk = INT_MIN;
                 for (int k = 0; k < G; k++)
@@ -628,6 +659,7 @@ run_again:
             }
             prev_fast = fast;
         }
+step_done:;
         int hi_rep = INT_MIN;
         for (int x = 0; x < 8 && !stopped; x++) {
             int32_t v = INT_MIN;

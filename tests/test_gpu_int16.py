@@ -618,6 +618,29 @@ def test_checkpoints_and_going_back_to_them(eng, shape):
         agatha_amd.set_debug_option("force_int16", 1)
 
 
+@pytest.mark.parametrize("lazy_max", [0, 2, 3, 8])
+def test_lazy_value_steps_of_the_one_pair_per_wave_shape(eng, lazy_max):
+    """Round 6: where a wave holds one pair (<64, P>) a value step whose calm test passed with room to spare answers for up to lazy_max steps
+    behind it -- no lower bound, no reduction over the lanes, no test on those (step_stats [23]); what the lanes keep meanwhile (the largest
+    last-column cell) enters the next test or, when the wave turns to key steps first, the bound of the running maximum.  Clean, noisy and broken
+    reads, z-drop within reach of the bound's slack and far from it, checkpoints every 256 steps and going back to them: bit-exact whatever
+    lazy_max; 0 = every value step is tested (the kernel as it was)."""
+    qs, ts = _broken_batch(83 + lazy_max, 200, 3000, 9000, broken=0.3, noisy=0.3)
+    agatha_amd.set_debug_option("force_int16", 0)
+    agatha_amd.set_debug_option("force_choice", 1)
+    try:
+        for p in (BASE, dict(BASE, z=120), dict(m=1, x=4, q=6, r=2, s=1, z=400, w=751), dict(BASE, z=-1)):
+            got, exp, st, kinds = _run_stats(eng, qs, ts, p, lazy_max=lazy_max, ck_min_steps=32)
+            assert _run_stats.choice[:2] == ("int16", 64)
+            assert _same(got, exp)
+            assert kinds[2] == 0
+            if lazy_max == 0: assert st[23] == 0
+            elif p.get("z", 400) >= 400 or p.get("z") == -1: assert st[23] > st[0] // 4, (st[0], st[23])          # (a test answers for lazy_max - 1 steps behind it: a third and more of the value steps even at 2)
+    finally:
+        agatha_amd.set_debug_option("force_choice", -1)
+        agatha_amd.set_debug_option("force_int16", 1)
+
+
 def test_two_wave_shape_moves_the_base_under_a_barrier(eng):
     """One pair on two waves, more workgroups than CUs (two and more per CU, so the waves of a pair drift apart in time) and
     scores that move the base of the representation several times per pair: the E hand-off values of the lanes at the wave

@@ -54,6 +54,7 @@ while time.time() < t_end:
     exp = O.align_batch(qb, tb, qo, to, ql, tl, O.make_params(**p), wide=True, model=O.MODEL_SLICES, threads=16)
     # (value steps of the int16 kernel: the window of key steps at a pair's end and the checkpoints vary as well)
     vs = dict(fast_margin=int(rng.choice([0, 1, 3, 8, 16, 64])), ck_min_steps=int(rng.choice([0, 16, 256, 4096])))
+    vs["lazy_max"] = (0, 1, 8, 8)[(trials >> 1) & 3]      # (lazy value steps of the one-pair-per-wave shapes, round 6)
     vs["fast_anchor"] = trials & 1            # (where the window of key steps is anchored: the shorter sequence's corner / the pair's end)
     for k_, v_ in os.environ.items():          # (tools/fuzz_one.py: override an option / a parameter of the trial)
         if k_.startswith("FUZZ_FORCE_"): vs[k_[11:].lower()] = int(v_)

@@ -34,6 +34,8 @@ for t in range(trials):
     span_, prob_ = C.c_int.in_dll(O.lib(), "agatha_lanes16_ck_span"), C.c_int.in_dll(O.lib(), "agatha_lanes16_probation")
     slots_ = C.c_int.in_dll(O.lib(), "agatha_lanes16_ck_slots")
     slots_.value = int(rng.choice([2, 2, 4, 8]))          # (2 = the kernel's two slots; a ring of more is the what-if of DESIGN.md 6 item 0)
+    lazy_, lazy_any_ = C.c_int.in_dll(O.lib(), "agatha_lanes16_lazy_max"), C.c_int.in_dll(O.lib(), "agatha_lanes16_lazy_any_shape")
+    lazy_.value, lazy_any_.value = int(rng.choice([0, 3, 8, 8])), 1        # (lazy value steps, round 6: the kernel uses them where a wave holds one pair; their arithmetic is the same on every shape)
     span_.value, prob_.value, margin = int(rng.choice([0, 64, 128, 256])), int(rng.integers(0, 2)), int(rng.choice([1, 4, 12, 40]))
     sc2, qe2, te2, kind2, _ = O.lanes16_batch(qb, tb, qo, to, ql, tl, prm, G, S, threads=8, value_step_margin=margin)
     if not (np.array_equal(e[0], sc2) and np.array_equal(e[1], qe2) and np.array_equal(e[2], te2)):
@@ -41,7 +43,7 @@ for t in range(trials):
         print("MISMATCH (decisions) trial", t, "w", w, "z", z, "s", s, "scores", (m, x, q, r), "span", span_.value, "slots", slots_.value, "probation", prob_.value, "margin", margin,
               "pairs", np.nonzero((e[0] != sc2) | (e[1] != qe2) | (e[2] != te2))[0][:5])
     kinds_seen = kinds_seen + np.bincount(kind2, minlength=5)[:5] if "kinds_seen" in dir() else np.bincount(kind2, minlength=5)[:5]
-    span_.value = prob_.value = 0; slots_.value = 2
+    span_.value = prob_.value = 0; slots_.value = 2; lazy_.value, lazy_any_.value = 8, 0
     if (kind == 0).any():
         gmin = min(gmin, st[0]); gmax = max(gmax, st[1]); garb = max(garb, st[2]); rmin = min(rmin, st[3])
 print("trials", trials, "mismatching trials", bad, "pairs", npairs, "bailed", nb)

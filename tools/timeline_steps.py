@@ -30,6 +30,7 @@ A = np.stack([fast, keys, np.ones_like(fast)], 1)
 coef, *_ = np.linalg.lstsq(A, life, rcond=None)
 print(f"align {ms:.2f} ms, {len(t)} waves, schedule {b.schedule_info()}, kernel choice {b.kernel_choice()}, step stats {b.step_stats()[:4]}")
 print("wave end us: min %.0f p10 %.0f median %.0f p90 %.0f p99 %.0f max %.0f ; start max %.0f" % (en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), np.percentile(en, 99), en.max(), st.max()))
+print("lazy value steps (one pair per wave: no lower bound, no reduction, no test): %.1f %% of the value steps" % (100.0 * t[:, 7].sum() / max(fast.sum(), 1)))
 print("steps per wave: min %d median %d max %d ; key steps per wave: min %d median %d p90 %d max %d" % (steps.min(), np.median(steps), steps.max(), keys.min(), np.median(keys), np.percentile(keys, 90), keys.max()))
 print("fit life = %.3f us x value steps + %.3f us x key steps + %.0f us ; mean life %.0f us = %.1f %% of the kernel" % (coef[0], coef[1], coef[2], life.mean(), 100 * life.mean() / en.max()))
 late = en > np.percentile(en, 99)
