@@ -47,6 +47,19 @@ print({k: "%.4e (%d launches)" % (v, len(agg[k])) for k, v in sorted(m.items())}
 if "SQ_INSTS_VALU" in m: print("issued VALU lane-ops per cell (C1, 1.43658e11 cells): %.3f" % (m["SQ_INSTS_VALU"] * 64 / 1.43658e11))
 PYEOF
         ;;
+    pmcx)       # pmcx <config> <counter> ...: one counter pass of `bench.py --config <config>`, mean per launch of the int16 kernel (where a lone wave's time goes: the WAIT / ACTIVE / LEVEL counters)
+        local c=$1; shift
+        rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/pmcx_$c -o pmc -- $BENCHQ --config $c > /dev/null 2>> $out/pmcx.err
+        python3 - <<PYEOF | tee -a $out/pmcx.txt
+import csv, glob, collections
+agg = collections.defaultdict(list)
+for f in glob.glob("$out/pmcx_$c/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "align16_kernel" in r["Kernel_Name"]: agg[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (k, n), v in sorted(agg.items()):
+    if max(v) > 0: print("$c %-42s %-24s mean %.4e max %.4e (%d launches)" % (k, n, sum(v) / len(v), max(v), len(v)))
+PYEOF
+        ;;
     pcsample)   # PC sampling of the headline kernel (beta; may be refused on the box)
         timeout 300 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-unit time --pc-sampling-method host_trap --pc-sampling-interval ${1:-500} \
             --kernel-trace --output-format csv -d $out/pcs -o pcs -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gasal-api > $out/pcs.json 2> $out/pcs.err
