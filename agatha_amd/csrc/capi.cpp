@@ -63,8 +63,9 @@ DebugOption g_opts[] = {
     {"ck_min_steps", "AGATHA_AMD_CK_MIN_STEPS", {384}},    // int16 kernel: pairs of at least this many steps take checkpoints (0: none do; 1024 until late in round 4: 3 kb pairs with broken reads among them, 22 -> 19 ms)
     {"poison_state", "AGATHA_AMD_POISON_STATE", {0}},     // tests: n > 0 = the int16 kernel writes the n-th suspended pair of a launch with a garbage step counter; 1000 + n = the same behind a flag that lets it pass the resume check, for the bound inside the step loop (see AlignLaunch::poison_state, agatha_amd_guard_stats)
     {"lazy_max", "AGATHA_AMD_LAZY_MAX", {8}},             // int16 kernel, one pair per wave: lazy value steps -- a calm test that passed with room to spare answers for up to this many steps behind it (no lower bound, no reduction, no test on those); 0 = every value step is tested
+    {"tb_value_steps", "AGATHA_AMD_TB_VALUE_STEPS", {1}},  // traceback pass of the int16 kernel: value steps (1, round 6) or key steps only (0)
 };
-enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_FLAT_DETECT, OPT_FLAT_PERCENT, OPT_CLEANUP_MIN_STEPS, OPT_PROBATION, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_POISON_STATE, OPT_LAZY_MAX, OPT_COUNT };
+enum { OPT_MAX_BLOCKS, OPT_NO_DEAL, OPT_NO_INT16, OPT_FORCE_INT16, OPT_FORCE_CHOICE, OPT_NO_MIGRATE, OPT_MIG_TIMEOUT_US, OPT_MIG_FRESH_TIMEOUT_US, OPT_MIG_TEST_DELAY_US, OPT_PRIO_SLICE, OPT_PRIO_DUTY, OPT_TIMELINE, OPT_FORCE_SPLIT, OPT_CK_NEWER, OPT_CK_SHIFT, OPT_LAT_BLOCKS, OPT_NO_SPLIT, OPT_PRIO_FINE, OPT_FAST_MARGIN, OPT_FAST_ANCHOR, OPT_STATIC_CK, OPT_WIN_CAP_MIN, OPT_WIN_CAP_DIV, OPT_FLAT_DETECT, OPT_FLAT_PERCENT, OPT_CLEANUP_MIN_STEPS, OPT_PROBATION, OPT_NO_POOL, OPT_MIG_IDENTITY, OPT_CK_MIN_STEPS, OPT_POISON_STATE, OPT_LAZY_MAX, OPT_TB_VALUE_STEPS, OPT_COUNT };
 std::once_flag g_opts_once;
 void init_opts()
 {
@@ -424,6 +425,7 @@ static int align_impl(void* stream, const uint32_t* d_packed_query, const uint32
     L.guard_stats = queue + 64;
     L.poison_state = opt(OPT_POISON_STATE);
     L.lazy_max = std::min(std::max(opt(OPT_LAZY_MAX), 0), 8);
+    L.tb_value_steps = opt(OPT_TB_VALUE_STEPS) != 0;
     L.score_limit = score_limit;
     L.force_cmp = (tb || sc->match < -128 || sc->match > 127 || sc->mismatch < -127 || sc->mismatch > 128) ? 1 : 0;
     L.tb_codes = nullptr; L.tb_off = nullptr; L.tb_pass = nullptr; L.tb_plan = nullptr; L.tb_lanes = 0;

@@ -70,6 +70,7 @@ struct AlignLaunch {
     // by the debug option poison_state (tests).  Non-zero [0] / [1] means memory the kernel owns was corrupted or its state machine has a bug:
     // the results are still right (the int32 kernel redoes those pairs), and the host says so loudly.
     unsigned int* guard_stats;
+    int tb_value_steps;            // traceback pass on the int16 kernel: 1 = value steps as in the score-only kernel (round 6), 0 = key steps only (debug option tb_value_steps)
     int lazy_max;                  // packed-int16 kernel, one pair per wave, value steps: a calm test that passed with room to spare answers for at most this many steps behind it (debug option lazy_max; 0 = every value step is tested)
     int poison_state;              // tests (debug option poison_state): n > 0 = the n-th suspended state of the launch is written with a garbage step counter (n + 1000: behind a flag that lets it pass the resume check, so that only the bound inside the step loop can end the pair)
     unsigned int* step_stats;      // device: [0] value wave-steps, [1] key wave-steps, [2] pairs started over, [3] pairs started, [23] lazy value wave-steps (int16 kernel)

@@ -226,8 +226,14 @@ def test_the_int16_kernel_records_the_codes(eng, w, z, lo, hi, n, shape):
         t = bytearray(ts[k]); h = len(t) * 2 // 3
         t[h:] = bytes(synth.random_seq(rng, len(t) - h)); ts[k] = bytes(t)
     got, st, cfg = _traceback(eng, qs, ts, stats=True, w=w, z=z)
-    assert cfg == shape and st[3] >= n - (n + 6) // 7 - 2 and st[0] == 0 and st[1] > 0        # pairs started on key steps only
+    # (round 6: the pass runs value steps like the score-only kernel; a pair a value step cannot decide starts over and writes the same codes again)
+    assert cfg == shape and st[3] >= n - (n + 6) // 7 - 2 and st[0] > st[1] > 0
     assert _check(qs, ts, got, threads=16, w=w, z=z) > n // 2
+    # ... and with key steps only (the pass of rounds 4-5): the same bytes
+    with agatha_amd.debug_options(tb_value_steps=0):
+        gotk, stk, _ = _traceback(eng, qs, ts, stats=True, w=w, z=z)
+    assert stk[0] == 0 and stk[1] > 0
+    assert all((a == b).all() for a, b in zip(got[:3], gotk[:3])) and got[3] == gotk[3]
     agatha_amd.set_debug_option("no_int16", 1)
     try:
         ref, st32, _ = _traceback(eng, qs, ts, stats=True, w=w, z=z)
