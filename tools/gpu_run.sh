@@ -47,9 +47,9 @@ print({k: "%.4e (%d launches)" % (v, len(agg[k])) for k, v in sorted(m.items())}
 if "SQ_INSTS_VALU" in m: print("issued VALU lane-ops per cell (C1, 1.43658e11 cells): %.3f" % (m["SQ_INSTS_VALU"] * 64 / 1.43658e11))
 PYEOF
         ;;
-    pmcx)       # pmcx <config> <counter> ...: one counter pass of `bench.py --config <config>`, mean per launch of the int16 kernel (where a lone wave's time goes: the WAIT / ACTIVE / LEVEL counters)
+    pmcx)       # pmcx <config> <counter> ...: one counter pass of `bench.py --config <config> $PMCX_ARGS`, mean per launch of the int16 kernel (where a lone wave's time goes: the WAIT / ACTIVE / LEVEL counters)
         local c=$1; shift
-        rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/pmcx_$c -o pmc -- $BENCHQ --config $c > /dev/null 2>> $out/pmcx.err
+        rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/pmcx_$c -o pmc -- $BENCHQ --config $c $PMCX_ARGS > /dev/null 2>> $out/pmcx.err
         python3 - <<PYEOF | tee -a $out/pmcx.txt
 import csv, glob, collections
 agg = collections.defaultdict(list)
