@@ -31,6 +31,14 @@ same_simd = same_cu & (simd[a] == simd[c])
 print("workgroups", len(a), "both waves on one CU", int(same_cu.sum()), "on one SIMD", int(same_simd.sum()))
 for name, m in (("same SIMD", same_simd), ("different SIMDs", ~same_simd)):
     if m.any(): print("  %-16s %4d workgroups: us per step median %.3f (steps median %d)" % (name, m.sum(), np.median((life[a] / steps[a])[m]), np.median(steps[a][m])))
+t0 = t[t[:, 1] != 0, 0].min()
+lw = np.concatenate([a, c])
+print("long pairs' waves: start us min %.0f max %.0f, end us min %.0f median %.0f max %.0f" % ((t[lw, 0].min() - t0) / 100.0, (t[lw, 0].max() - t0) / 100.0, (t[lw, 1].min() - t0) / 100.0, np.median(t[lw, 1] - t0) / 100.0, (t[lw, 1].max() - t0) / 100.0))
+print("all waves: last end us %.0f" % ((t[t[:, 1] != 0, 1].max() - t0) / 100.0))
+keyl = ((xcc[lw] * 8 + se[lw]) * 16 + cu[lw]) * 4 + simd[lw]
+ul, cl = np.unique(keyl, return_counts=True)
+cul, ccl = np.unique(keyl >> 2, return_counts=True)
+print("long pairs' waves: SIMDs used", len(ul), "waves per SIMD histogram", np.bincount(cl).tolist(), "; CUs used", len(cul), "waves per CU histogram", np.bincount(ccl).tolist())
 # how many waves share a SIMD at all (other workgroups)
 key = ((xcc * 8 + se) * 16 + cu) * 4 + simd
 live = t[:, 1] != 0
