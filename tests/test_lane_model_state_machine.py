@@ -136,3 +136,32 @@ def test_probation_returns_a_pair_to_value_steps_and_changes_no_result(knobs):
         assert kinds[4] > 0 and kinds[5] > 0, kinds                   # went back (and stayed) / went back, gave up again, started over
     finally:
         prob.value = 0
+
+
+@pytest.mark.parametrize("scoring", [dict(m=2, x=4, q=4, r=2, z=400), dict(m=1, x=4, q=6, r=2, z=400), dict(m=2, x=4, q=4, r=2, z=120), dict(m=2, x=4, q=4, r=2, z=-1)])
+def test_lazy_value_steps_change_no_result(knobs, scoring):
+    """Round 6 ("lazy value steps"; align16_step_blocks.inc / align16_step_maxima.inc: `lazy`, `skip_until`, `acc_hi`): where a wave
+    holds one pair a calm test that passed with room to spare answers for up to lazy_max - 1 steps behind it; the kernel computes no lower bound,
+    reduces nothing and tests nothing on those.  The lane model mirrors the rule (agatha_lanes16_lazy_max; on every shape with
+    agatha_lanes16_lazy_any_shape, the kernel's choice being G >= 64): clean reads and reads that z-drop ends, with and without checkpoints, the
+    window as it is and capped so that pairs end without the cell of their maximum -- every result the oracle's whatever lazy_max, and the shape the
+    kernel uses it on (64 lanes, two slots per lane) as well as the throughput shape."""
+    lib = O.lib()
+    lazy, any_shape = C.c_int.in_dll(lib, "agatha_lanes16_lazy_max"), C.c_int.in_dll(lib, "agatha_lanes16_lazy_any_shape")
+    (qb, qo, ql), (tb, to, tl) = _batch(23, 120)
+    w = 751 if scoring["z"] != 120 else 300
+    p = O.make_params(w=w, **scoring)
+    exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=8)
+    saved = (lazy.value, any_shape.value)
+    try:
+        for G, S in ((64, 2), (16, 6)):
+            if G * S * 8 < w + 8: continue
+            for lm in (0, 2, 8):
+                for span, cap in ((0, (128, 16)), (64, (128, 16)), (128, (24, 1 << 20))):
+                    lazy.value, any_shape.value = lm, 1
+                    knobs["span"].value = span
+                    knobs["cap_min"].value, knobs["cap_div"].value = cap
+                    got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, G, S, threads=8, value_step_margin=12)
+                    assert all((np.asarray(g) == np.asarray(e)).all() for g, e in zip(got[:3], exp)), (G, S, lm, span, cap)
+    finally:
+        lazy.value, any_shape.value = saved
