@@ -347,6 +347,7 @@ static __thread long long l16_tl_steps[2];
 int agatha_lanes16_trace = 0;             /* tools: print every step's mode, bound and whether the cell of the maximum is known (stderr) */
 int agatha_lanes16_old_window = 0;        /* tools: round 4's rule for the window of key steps (3/2 (slack + 7 ge) i / best) */
 int agatha_lanes16_lazy_max = 8;          /* lazy value steps (round 6, one pair per wave: G >= 64): a passed test answers for at most this many steps behind it (0 = every step is tested) */
+long long agatha_lanes16_lazy_steps = 0;  /* tests: value steps on which nothing was tested (all threads; not atomic -- a count that is zero or not) */
 int agatha_lanes16_lazy_any_shape = 0;    /* tests / tools: the rule on every shape (its arithmetic does not depend on the shape; the kernel uses it where a wave holds one pair) */
 
 int agatha_model_lanes16(const char *qs, int Q, const char *rs, int R, const lm_params_t *pr,
@@ -607,6 +608,7 @@ run_again:
                 int64_t ub = HI == INT_MIN ? INT_MIN : (int64_t)HI + base - (int64_t)ge * (8 * i + 7) + slack;
                 if (lazy) {
                     /* nothing is tested: the last test answers for this step */
+                    agatha_lanes16_lazy_steps++;
                     if (ub > acc_ub) acc_ub = ub;
                     if (lo_prev_abs != INT_MIN) lo_prev_abs -= 8 * (int64_t)ge;
                     HI = INT_MIN;                                   /* (no rebase on such a step either) */

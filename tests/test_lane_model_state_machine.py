@@ -153,15 +153,19 @@ def test_lazy_value_steps_change_no_result(knobs, scoring):
     p = O.make_params(w=w, **scoring)
     exp = O.align_batch(qb, tb, qo, to, ql, tl, p, wide=True, model=O.MODEL_STEPS, threads=8)
     saved = (lazy.value, any_shape.value)
+    n_lazy = C.c_longlong.in_dll(lib, "agatha_lanes16_lazy_steps")
     try:
         for G, S in ((64, 2), (16, 6)):
             if G * S * 8 < w + 8: continue
             for lm in (0, 2, 8):
                 for span, cap in ((0, (128, 16)), (64, (128, 16)), (128, (24, 1 << 20))):
                     lazy.value, any_shape.value = lm, 1
+                    n_lazy.value = 0
                     knobs["span"].value = span
                     knobs["cap_min"].value, knobs["cap_div"].value = cap
                     got = O.lanes16_batch(qb, tb, qo, to, ql, tl, p, G, S, threads=8, value_step_margin=12)
                     assert all((np.asarray(g) == np.asarray(e)).all() for g, e in zip(got[:3], exp)), (G, S, lm, span, cap)
+                    if lm == 0: assert n_lazy.value == 0
+                    if lm == 8 and scoring["z"] in (400, -1): assert n_lazy.value > 1000, n_lazy.value
     finally:
         lazy.value, any_shape.value = saved
