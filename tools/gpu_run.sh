@@ -74,11 +74,12 @@ PYEOF
         [ "$lib" = tree ] && lib= || lib=$PWD/ab/$lib
         echo "== skew lib=${lib:-tree} scoring=$sc" | tee -a $out/skew.txt
         AGATHA_AMD_LIB=$lib SCORING=$sc timeout 600 python3 tools/gpu_skew.py 2>&1 | tee -a $out/skew.txt ;;
-    fuzz)       # fuzz <lib|tree> <seconds>: the three randomised parity sweeps
+    fuzz)       # fuzz <lib|tree> <seconds>: the randomised parity sweeps (static schedule, mixed short reads, long reads)
         local lib=$1 s=${2:-60}
         [ "$lib" = tree ] && lib= || lib=$PWD/ab/$lib
         AGATHA_AMD_LIB=$lib timeout $((s + 120)) python3 tools/gpu_fuzz_mig.py $s 2>&1 | tail -3 | tee -a $out/fuzz.txt
-        AGATHA_AMD_LIB=$lib timeout $((s + 120)) python3 tools/gpu_fuzz.py $s 2>&1 | tail -3 | tee -a $out/fuzz.txt ;;
+        AGATHA_AMD_LIB=$lib timeout $((s + 120)) python3 tools/gpu_fuzz.py $s 2>&1 | tail -3 | tee -a $out/fuzz.txt
+        AGATHA_AMD_LIB=$lib timeout $((s / 2 + 180)) python3 tools/gpu_fuzz_long.py $((s / 2)) 2>&1 | tail -14 | tee -a $out/fuzz.txt ;;
     curve)      # throughput as a function of the batch size (tools/batch_size_curve.py)
         timeout 900 python3 tools/batch_size_curve.py "$@" 2>&1 | tee $out/batch_size_curve.txt ;;
     configs)    # bench lines of the other BASELINE shapes
